@@ -1,0 +1,154 @@
+/*
+ * rln.h -- C ABI of the MI355X-native lane-segmentation hot path ("right lane network").
+ *
+ * Drop-in boundary for the FC-DenseNet training / inference path of
+ * timurlenk07/sim2real_lane_segment.  The reference has no native code: each entry point below
+ * replaces a group of torch ops at the cited reference lines (paths relative to
+ * rightLaneNetwork/).  Python binds this with ctypes (sim2real_lane_segment_amd/_lib.py).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter name ends in _host;
+ *   - tensors are contiguous NCHW fp32, labels are int64 (torch.long);
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); all work is enqueued on it,
+ *     nothing synchronises the device;
+ *   - every function returns 0 on success, <0 for an rln error, >0 for a hipError_t;
+ *     rln_last_error() returns a thread-local message;
+ *   - one rln_ctx per (process, device); a ctx is not thread-safe.
+ */
+#ifndef RLN_H_
+#define RLN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RLN_MAX_BLOCKS 8
+
+enum rln_error {
+  RLN_OK = 0,
+  RLN_ERR_ARG = -1,       /* bad argument / shape */
+  RLN_ERR_STATE = -2,     /* call order (nothing bound, no forward before backward, ...) */
+  RLN_ERR_WORKSPACE = -3, /* workspace missing or too small */
+  RLN_ERR_UNSUPPORTED = -4
+};
+
+/* Constructor knobs of FCDenseNetFeatureExtractor / FCDenseNetClassifier
+ * (models/FCDenseNet/tiramisu.py:21-24,112-118) + the constants of the layers
+ * (layers.py:8,12: BatchNorm2d eps 1e-5 momentum 0.1, Dropout2d 0.2). */
+typedef struct rln_config {
+  int in_channels;
+  int n_down;
+  int down_blocks[RLN_MAX_BLOCKS];
+  int n_up;
+  int up_blocks[RLN_MAX_BLOCKS];
+  int bottleneck_layers;
+  int growth_rate;
+  int first_conv_channels;
+  int n_classes;
+  float temperature;
+  float bn_eps;
+  float bn_momentum;
+  float drop_p;
+} rln_config;
+
+typedef struct rln_ctx rln_ctx;
+
+/* tensor kinds reported by rln_tensor_info */
+enum { RLN_T_PARAM = 0, RLN_T_RUNNING_MEAN = 1, RLN_T_RUNNING_VAR = 2, RLN_T_NUM_BATCHES = 3 };
+
+const char* rln_last_error(void);
+int rln_version(void);
+
+/* Builds the execution plan for a net (replaces the module construction in
+ * trainingModules/TrainingBase.py:27-40 / tiramisu.py:21-87). Host-only, allocates nothing on the device. */
+int rln_create(const rln_config* cfg, rln_ctx** out);
+void rln_destroy(rln_ctx* ctx);
+
+/* ---- parameter arenas ------------------------------------------------------------------
+ * Parameters live in ONE flat fp32 arena laid out in forward execution order (so that gradients
+ * complete back-to-front during backward and DDP buckets are contiguous slices); BN running
+ * statistics live in a second flat fp32 arena, num_batches_tracked in a flat int64 arena.
+ * rln_tensor_info enumerates every state_dict entry (434 for FCDenseNet67, reference key names)
+ * with its arena offset, so the host can create views with the reference's names and shapes. */
+int rln_num_tensors(const rln_ctx* ctx);
+int64_t rln_param_count(const rln_ctx* ctx);  /* floats in the parameter (and gradient) arena */
+int64_t rln_bnstat_count(const rln_ctx* ctx); /* floats in the running-stat arena */
+int64_t rln_nbt_count(const rln_ctx* ctx);    /* int64 entries (one per BatchNorm2d) */
+int rln_tensor_info(const rln_ctx* ctx, int idx, char* name, int name_cap, int* kind, int64_t* offset,
+                    int* ndim, int64_t shape[4]);
+int rln_feature_channels(const rln_ctx* ctx);
+/* number of Dropout2d calls in one forward and total channels over them (mask layout: call-major,
+ * each call [N, C_call]) */
+int rln_num_dropouts(const rln_ctx* ctx);
+int64_t rln_dropout_channels(const rln_ctx* ctx, int* per_call /* may be NULL, else [num_dropouts] */);
+
+int rln_bind_params(rln_ctx* ctx, float* params, float* grads, float* bn_running, int64_t* num_batches_tracked);
+
+/* ---- workspace -------------------------------------------------------------------------
+ * Activation stacks, gradient stacks, statistics and scratch for a given input geometry.
+ * The host allocates (torch caching allocator) and hands the block over. */
+size_t rln_workspace_bytes(const rln_ctx* ctx, int n, int h, int w, int with_backward);
+int rln_set_workspace(rln_ctx* ctx, void* ws, size_t bytes, int n, int h, int w, int with_backward);
+
+/* ---- forward: TrainingBase.forward (TrainingBase.py:54-57) = featureExtractor (tiramisu.py:89-106)
+ * + classifier (tiramisu.py:120-125).
+ *   training     : 1 = BatchNorm batch statistics + running-stat update + Dropout2d, 0 = eval
+ *   drop_scales  : NULL -> masks drawn on the device from `seed`; else [sum_c N*C_call] floats holding
+ *                  0 or 1/(1-p) per (call, sample, channel) (parity tests inject the oracle's masks)
+ *   probs_out    : [N, n_classes, H, W] softmax probabilities (or scaled logits if use_softmax==0); may be NULL
+ *   feat_out     : [N, feature_channels, H, W] L2-normalised features (F.normalize, tiramisu.py:105); may be NULL
+ */
+int rln_forward(rln_ctx* ctx, const float* x, int n, int h, int w, int training, const float* drop_scales,
+                uint64_t seed, float* probs_out, float* feat_out, int use_softmax, void* stream);
+
+/* Classifier alone on caller-provided features (FCDenseNetClassifier.forward, tiramisu.py:120-125). */
+int rln_classifier_forward(rln_ctx* ctx, const float* feat, int n, int h, int w, float* out, int use_softmax,
+                           void* stream);
+
+/* ---- loss: SimpleTrainModule.training_step (SimpleTrain.py:15-20) / evaluate_batch (TrainingBase.py:84-87)
+ *   weighted=1: class weights = 1/count per batch (getClassWeight, TrainingBase.py:12-23), cross_entropy on the
+ *   probabilities (double softmax); weighted=0: plain mean CE.
+ *   out[0]=loss, out[1]=accuracy in [0,1], out[2]=number of labels >= n_classes (reference asserts on those),
+ *   out[3..3+n_classes) = class pixel counts.  argmax_out: optional int64 [N,H,W] (torch.max(outputs,1)[1]).
+ *   confusion_out: optional int64 [n_classes*n_classes], row = label, col = prediction. */
+int rln_loss(rln_ctx* ctx, const float* probs, const int64_t* y, int n, int h, int w, int weighted, float* out,
+             int64_t* argmax_out, int64_t* confusion_out, void* stream);
+
+/* ---- backward of loss∘classifier∘featureExtractor for the last training rln_forward + rln_loss(weighted)
+ * (autograd of the torch graph in the reference).  Fills the bound gradient arena (overwrites).
+ * The plan is cut into rln_backward_segments() segments that complete contiguous slices of the gradient
+ * arena back to front; [seg_begin, seg_end) lets the host interleave gradient all-reduce with backward.
+ * grad range completed by a segment: rln_backward_segment_range. loss_scale multiplies d(loss). */
+int rln_backward_segments(const rln_ctx* ctx);
+int rln_backward_segment_range(const rln_ctx* ctx, int seg, int64_t* grad_begin, int64_t* grad_end);
+int rln_backward(rln_ctx* ctx, float loss_scale, int seg_begin, int seg_end, void* stream);
+
+/* ---- optimiser: torch.optim.AdamW single group as configured in SimpleTrain.py:27-28, on flat arenas. */
+int rln_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t count, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+
+/* ---- single-op entry points (parity tests exercise each kernel family alone) --------------
+ * rln_op_conv_bnrelu: y = scale[n,o] * (conv_KxK(relu(a[c]*x+b[c])) + bias[o]) written at channel offset
+ *   out_coff of a [N, out_ctot, H, W] tensor (layers.py:8-12 with BN folded to a,b; a==NULL -> raw input).
+ *   pool=1 appends MaxPool2d(2) (layers.py:46-52) and writes [N, out_ctot, H/2, W/2] + uint8 argmax idx.
+ *   stats: optional [cout,2] per-channel (sum, sum of squares) of what was written. */
+int rln_op_conv_bnrelu(const float* x, int n, int cin, int x_ctot, int x_coff, int h, int w, const float* a,
+                       const float* b, const float* weight, const float* bias, int cout, int ksize,
+                       const float* scale, float* out, int out_ctot, int out_coff, int pool, uint8_t* pool_idx,
+                       float* stats, void* workspace, size_t workspace_bytes, void* stream);
+/* rln_op_convt: ConvTranspose2d(k3,s2,p0)+bias cropped top-left to (hout,wout) (layers.py:58-67,82-86). */
+int rln_op_convt(const float* x, int n, int cin, int h, int w, const float* weight, const float* bias, int cout,
+                 float* out, int out_ctot, int out_coff, int hout, int wout, void* stream);
+
+/* rln_op_classifier: FCDenseNetClassifier.forward on caller-provided weights (tiramisu.py:120-125):
+ * out[n,k,p] = softmax_k((sum_c w[k,c]*feat[n,c,p] + b[k]) / T). */
+int rln_op_classifier(const float* feat, int n, int c, int hw, const float* w, const float* b, int ncls, float T,
+                      float* out, int use_softmax, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RLN_H_ */

@@ -1,0 +1,102 @@
+// Implicit-GEMM convolution family on v_mfma_f32_16x16x4_f32 (exact fp32).
+//
+// One kernel template covers every "pixel tile x output channels" contraction of the path:
+//   conv3x3 / conv1x1 forward with the BatchNorm affine + ReLU folded into LDS staging
+//   (layers.py:8-11,46-49), MaxPool2d(2) epilogue (layers.py:52), ConvTranspose2d forward by output
+//   parity class (layers.py:61-63), and the data gradients of all three.
+#pragma once
+#include "common.h"
+
+namespace rln {
+
+enum { PRO_RAW = 0, PRO_BNRELU = 1, PRO_S2D = 2 };
+enum { EPI_STORE = 0, EPI_POOL = 1, EPI_DGRAD = 2 };
+enum { TM_ID = 0, TM_FLIP = 1, TM_CONVT = 2 };
+
+struct IgemmParams {
+  // K-side operand (the tensor the taps slide over), logical channels [0,K) of an NCHW view
+  const float* in;
+  long long in_ns;  // sample stride (elements)
+  int in_cs;        // channel stride (elements) ; rows are Win apart
+  int Hin, Win, K;
+  const float* pa;  // PRO_BNRELU: z = max(pa[c]*x + pb[c], 0)
+  const float* pb;
+  // weights: element (j, k, tap) at w[j*w_js + k*w_ks + tap]
+  const float* w;
+  long long w_js, w_ks;
+  int tapmode;
+  int J;  // output channels
+  // tile grid space (= output grid, except convT-forward where out = 2*g + parity)
+  int GH, GW, tiles_x, tiles_y, ncls;
+  // output view
+  float* out;
+  long long out_ns;
+  int out_cs, Hout, Wout;
+  int out_vec;          // 1: rows are 16-byte aligned (float4 path legal)
+  const float* bias;    // [J] or null
+  const float* nscale;  // [N][J] or null (Dropout2d scale per sample/channel)
+  const float* cscale;  // [J] or null
+  float* stat_partial;  // [blocks][J][2] or null
+  unsigned char* pool_idx;  // EPI_POOL: [N][J][Hout][Wout]
+  // EPI_DGRAD extras: S = activation view the BN of this layer normalised, G(out) accumulates gamma*gy
+  const float* S;
+  long long s_ns;
+  const float* ea;
+  const float* eb;
+  const float* emean;
+  const float* einvstd;
+  const float* egamma;
+  int acc_lo, acc_hi;  // channels in [acc_lo,acc_hi) accumulate into out, others overwrite
+};
+
+// which compiled variant
+enum IgemmKind {
+  IG_CONV3_BN = 0,   // KS3 NT1 PRO_BNRELU EPI_STORE   dense layer forward
+  IG_CONV3_RAW = 1,  // KS3 NT1 PRO_RAW    EPI_STORE   first conv, convT forward (ncls=4)
+  IG_CONV1_POOL = 2, // KS1 NT4 PRO_BNRELU EPI_POOL    transition down forward
+  IG_DGRAD3 = 3,     // KS3 NT4 PRO_RAW    EPI_DGRAD   dense layer data gradient
+  IG_DGRAD1 = 4,     // KS1 NT4 PRO_RAW    EPI_DGRAD   transition down data gradient
+  IG_S2D3 = 5,       // KS3 NT4 PRO_S2D    EPI_STORE   convT data gradient
+  IG_CONV1_BN = 6,   // KS1 NT4 PRO_BNRELU EPI_STORE   1x1 conv without pool (generic / tests)
+};
+
+// tile: 0 -> 8x32, 1 -> 16x16
+int igemm_launch(IgemmKind kind, int tile, const IgemmParams& p, int N, hipStream_t stream);
+void igemm_tile_dims(IgemmKind kind, int tile, int* th, int* tw);
+int igemm_pick_tile(int gh, int gw);
+// number of stat-partial blocks a launch produces
+inline long long igemm_stat_blocks(const IgemmParams& p, int N) {
+  return (long long)p.ncls * p.tiles_x * p.tiles_y * N;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient family: dW[m][n][tap] = sum_pixels U[m][p] * V[n][p + tap]  (or roles swapped)
+struct WgradParams {
+  // U: un-shifted operand (raw), V: shifted operand (PRO_RAW / PRO_BNRELU / PRO_S2D)
+  const float* u;
+  long long u_ns;
+  int u_cs, Uc;  // Uc channels
+  const float* v;
+  long long v_ns;
+  int v_cs, Vc, Hv, Wv;
+  const float* pa;
+  const float* pb;
+  int GH, GW, tiles_x, tiles_y;  // tile grid (U's spatial dims)
+  int N;
+  int items_per_chunk, nchunks;
+  float* partial;         // [nchunks][wsize]
+  long long wsize;
+  long long m_stride, n_stride;  // output index = m*m_stride + n*n_stride + tap
+};
+enum WgradKind {
+  WG_DENSE3 = 0,  // M=U (dY 16ch), N=V (z = relu(a*S+b)), 9 taps
+  WG_RAW3 = 1,    // as above, V raw (first conv)
+  WG_PW1 = 2,     // 1x1: M=U (dY), N=V (z), MT=4
+  WG_CONVT = 3,   // M=V (dU, S2D, 16ch), N=U (convT input raw), 9 taps
+};
+int wgrad_launch(WgradKind kind, int tile, const WgradParams& p, hipStream_t stream);
+void wgrad_tile_dims(WgradKind kind, int tile, int* th, int* tw);
+int wgrad_pick_tile(int gh, int gw);
+void wgrad_block_dims(WgradKind kind, int* m_per_block, int* n_per_block);
+
+}  // namespace rln

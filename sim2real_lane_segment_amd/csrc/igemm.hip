@@ -1,0 +1,666 @@
+// Implicit-GEMM convolution kernels for gfx950 on v_mfma_f32_16x16x4_f32 (see igemm.h).
+//
+// Block = 256 threads = 4 waves.  A block owns one TH x TW pixel tile (256 or 128 pixels =
+// 16-pixel M-tiles, MPW per wave) of one sample and NT*16 output channels.  The K loop walks the
+// input channels 16 at a time: the tile (+halo) of those channels is staged into LDS with the
+// BatchNorm affine + ReLU applied on the way (zero padding is applied AFTER the activation, as
+// Conv2d(padding=1) sees it), the matching weight slab is staged in MFMA B-operand order, then
+// every wave issues MPW*NT MFMAs per (4-channel group, tap).
+//
+// LDS layout: activations [16 ch][CHS] with CHS % 32 == 16 so that the A-operand read of a wave
+// (16 consecutive pixels x 4 channels) touches 64 distinct banks; weights [kgroup][tap][ntile][64]
+// so that the B-operand read is lane-linear.
+#include "igemm.h"
+
+namespace rln {
+
+template <int KS, int NT, int PRO, int EPI, int TH, int TW>
+struct IgCfg {
+  static constexpr int CK = 16;
+  static constexpr bool S2D = (PRO == PRO_S2D);
+  static constexpr int HALO = KS - 1;
+  static constexpr int PITCH = S2D ? (TW + 1) : (TW + HALO);
+  static constexpr int ROWS = S2D ? (TH + 1) : (TH + HALO);
+  static constexpr int PLANE = PITCH * ROWS;
+  static constexpr int POS = PLANE * (S2D ? 4 : 1);
+  static constexpr int CHS = round_mod32(POS, 16);
+  static constexpr int NPOS = cdiv(POS, 256);
+  static constexpr int NS = KS * KS;
+  static constexpr int IN_FLOATS = CK * CHS;
+  static constexpr int W_FLOATS = (CK / 4) * NS * NT * 64;
+  static constexpr int WE = 16 * NT * CK * NS;
+  static constexpr int NWE = cdiv(WE, 256);
+  static constexpr int OLS = TH * TW + 1;
+  static constexpr int POOL_FLOATS = (EPI == EPI_POOL) ? 16 * OLS : 0;
+  static constexpr int MAIN_FLOATS = cmax(IN_FLOATS + W_FLOATS, POOL_FLOATS);
+  static constexpr int RED_FLOATS = 4 * NT * 16 * 2;
+  static constexpr int LDS_BYTES = (MAIN_FLOATS + RED_FLOATS) * 4;
+  static constexpr int MPW = TH * TW / 64;
+  __host__ __device__ static constexpr int slot_off(int s) {
+    return S2D ? ((((s / 3) & 1) * 2 + ((s % 3) & 1)) * PLANE + ((s / 3) >> 1) * PITCH + ((s % 3) >> 1))
+               : ((s / KS) * PITCH + (s % KS));
+  }
+};
+
+template <int KS, int NT, int PRO, int EPI, int TH, int TW>
+__global__ __launch_bounds__(256) void igemm_k(const IgemmParams p) {
+  using C = IgCfg<KS, NT, PRO, EPI, TH, TW>;
+  constexpr int MPW = C::MPW;
+  static_assert(TW % 16 == 0 && (TH * TW) % 64 == 0, "tile must be whole M-tiles per wave");
+  extern __shared__ __align__(16) float smem[];
+  float* zl = smem;
+  float* wl = smem + C::IN_FLOATS;
+  float* red = smem + C::MAIN_FLOATS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, lj = lane & 15, lk = lane >> 4;
+  int bx = blockIdx.x;
+  const int tiles = p.tiles_x * p.tiles_y;
+  int cls = 0;
+  if (p.ncls > 1) {
+    cls = bx / tiles;
+    bx -= cls * tiles;
+  }
+  const int tile_y = bx / p.tiles_x, tile_x = bx - tile_y * p.tiles_x;
+  const int gy0 = tile_y * TH, gx0 = tile_x * TW;
+  const int n = blockIdx.z;
+  const int jbase = blockIdx.y * (NT * 16);
+  const int py = cls >> 1, px = cls & 1;
+
+  // ---- per-thread staging positions (independent of the channel) ----
+  int goff[C::NPOS], loff[C::NPOS];
+#pragma unroll
+  for (int i = 0; i < C::NPOS; ++i) {
+    const int e = tid + 256 * i;
+    goff[i] = -1;
+    loff[i] = -1;
+    if (e < C::POS) {
+      int iy, ix;
+      if constexpr (C::S2D) {
+        const int pl = e / C::PLANE, rem = e - pl * C::PLANE;
+        const int r = rem / C::PITCH, col = rem - r * C::PITCH;
+        iy = 2 * (gy0 + r) + (pl >> 1);
+        ix = 2 * (gx0 + col) + (pl & 1);
+      } else {
+        const int r = e / C::PITCH, col = e - r * C::PITCH;
+        iy = gy0 - C::HALO / 2 + r;
+        ix = gx0 - C::HALO / 2 + col;
+      }
+      loff[i] = e;
+      if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) goff[i] = iy * p.Win + ix;
+    }
+  }
+  int pixoff[MPW];
+#pragma unroll
+  for (int m = 0; m < MPW; ++m) {
+    const int q0 = (wave * MPW + m) * 16;
+    const int ty = q0 / TW, tx = q0 - ty * TW;
+    pixoff[m] = ty * C::PITCH + tx + lj;
+  }
+  unsigned smask = (1u << C::NS) - 1u;
+  if (p.tapmode == TM_CONVT) {
+    smask = 0;
+    for (int sy = 0; sy < 2; ++sy)
+      for (int sx = 0; sx < 2; ++sx)
+        if ((sy == 1 || py == 0) && (sx == 1 || px == 0)) smask |= 1u << (sy * 3 + sx);
+  }
+
+  f32x4 acc[MPW][NT];
+#pragma unroll
+  for (int m = 0; m < MPW; ++m)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const float* in_n = p.in + (long long)n * p.in_ns;
+  const int nchunk = (p.K + 15) >> 4;
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const int c0 = ch * 16;
+    if (ch > 0) __syncthreads();
+    // ---- stage 16 input channels (tile + halo), activation applied on the way ----
+#pragma unroll 4
+    for (int cc = 0; cc < 16; ++cc) {
+      const int c = c0 + cc;
+      const bool cv = c < p.K;
+      const float* src = in_n + (long long)c * p.in_cs;
+      float a = 1.f, b = 0.f;
+      if constexpr (PRO == PRO_BNRELU) {
+        if (cv) {
+          a = p.pa[c];
+          b = p.pb[c];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < C::NPOS; ++i) {
+        if (loff[i] >= 0) {
+          float v = 0.f;
+          if (cv && goff[i] >= 0) {
+            v = src[goff[i]];
+            if constexpr (PRO == PRO_BNRELU) v = fmaxf(fmaf(a, v, b), 0.f);
+          }
+          zl[cc * C::CHS + loff[i]] = v;
+        }
+      }
+    }
+    // ---- stage the weight slab in B-operand order ----
+#pragma unroll 4
+    for (int i = 0; i < C::NWE; ++i) {
+      const int e = tid + 256 * i;
+      if (e < C::WE) {
+        const int s = e % C::NS, t = e / C::NS;
+        const int cc = t & 15, jj = t >> 4;
+        const int j = jbase + jj, k = c0 + cc;
+        int tap;
+        if (p.tapmode == TM_ID) {
+          tap = s;
+        } else if (p.tapmode == TM_FLIP) {
+          tap = C::NS - 1 - s;
+        } else {
+          const int sy = s / 3, sx = s - sy * 3;
+          const int ky = (sy == 1) ? py : ((sy == 0 && py == 0) ? 2 : -1);
+          const int kx = (sx == 1) ? px : ((sx == 0 && px == 0) ? 2 : -1);
+          tap = (ky < 0 || kx < 0) ? -1 : ky * 3 + kx;
+        }
+        float v = 0.f;
+        if (j < p.J && k < p.K && tap >= 0) v = p.w[(long long)j * p.w_js + (long long)k * p.w_ks + tap];
+        wl[(((cc >> 2) * C::NS + s) * NT + (jj >> 4)) * 64 + (cc & 3) * 16 + (jj & 15)] = v;
+      }
+    }
+    __syncthreads();
+    // ---- MFMA ----
+    const int kgn = min(4, (p.K - c0 + 3) >> 2);
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+      if (kg < kgn) {
+        const float* zb = zl + (kg * 4 + lk) * C::CHS;
+#pragma unroll
+        for (int s = 0; s < C::NS; ++s) {
+          if ((smask >> s) & 1u) {
+            float bw[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bw[nt] = wl[((kg * C::NS + s) * NT + nt) * 64 + lane];
+#pragma unroll
+            for (int m = 0; m < MPW; ++m) {
+              const float a = zb[pixoff[m] + C::slot_off(s)];
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mfma16(a, bw[nt], acc[m][nt]);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  const long long blk_lin = (long long)n * gridDim.x + blockIdx.x;
+
+  if constexpr (EPI == EPI_STORE || EPI == EPI_DGRAD) {
+    const int S_ = (p.ncls > 1) ? 2 : 1;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int j = jbase + nt * 16 + lj;
+      const bool jv = j < p.J;
+      float s1 = 0.f, s2 = 0.f;
+      float bias_j = 0.f, sc = 1.f;
+      float ea = 0.f, eb = 0.f, emean = 0.f, einv = 0.f, egam = 0.f;
+      bool accum = false;
+      if constexpr (EPI == EPI_STORE) {
+        if (jv) {
+          if (p.bias) bias_j = p.bias[j];
+          if (p.nscale) sc = p.nscale[(long long)n * p.J + j];
+          if (p.cscale) sc *= p.cscale[j];
+        }
+      } else {
+        if (jv) {
+          ea = p.ea[j];
+          eb = p.eb[j];
+          emean = p.emean[j];
+          einv = p.einvstd[j];
+          egam = p.egamma[j];
+        }
+        accum = (j >= p.acc_lo) && (j < p.acc_hi);
+      }
+#pragma unroll
+      for (int m = 0; m < MPW; ++m) {
+        const int q = (wave * MPW + m) * 16 + lk * 4;
+        const int ty = q / TW, tx = q - ty * TW;
+        const int gy = gy0 + ty, gx = gx0 + tx;
+        if (!jv || gy >= p.GH) continue;
+        if constexpr (EPI == EPI_STORE) {
+          const int oy = gy * S_ + py;
+          if (oy >= p.Hout) continue;
+          float* dst = p.out + (long long)n * p.out_ns + (long long)j * p.out_cs + (long long)oy * p.Wout;
+          const int ox0 = gx * S_ + px;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = (acc[m][nt][r] + bias_j) * sc;
+          if (S_ == 1 && p.out_vec && ox0 + 3 < p.Wout) {
+            *reinterpret_cast<float4*>(dst + ox0) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              s1 += v[r];
+              s2 += v[r] * v[r];
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int ox = ox0 + r * S_;
+              if (gx + r < p.GW && ox < p.Wout) {
+                dst[ox] = v[r];
+                s1 += v[r];
+                s2 += v[r] * v[r];
+              }
+            }
+          }
+        } else {
+          const long long rowoff = (long long)j * p.out_cs + (long long)gy * p.GW + gx;
+          const float* sp = p.S + (long long)n * p.s_ns + rowoff;
+          float* gp = p.out + (long long)n * p.out_ns + rowoff;
+          float sv[4], gv[4];
+          const bool vec = p.out_vec && (gx + 3 < p.GW);
+          if (vec) {
+            const float4 t4 = *reinterpret_cast<const float4*>(sp);
+            sv[0] = t4.x; sv[1] = t4.y; sv[2] = t4.z; sv[3] = t4.w;
+            if (accum) {
+              const float4 g4 = *reinterpret_cast<const float4*>(gp);
+              gv[0] = g4.x; gv[1] = g4.y; gv[2] = g4.z; gv[3] = g4.w;
+            } else {
+              gv[0] = gv[1] = gv[2] = gv[3] = 0.f;
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const bool ok = gx + r < p.GW;
+              sv[r] = ok ? sp[r] : 0.f;
+              gv[r] = (ok && accum) ? gp[r] : 0.f;
+            }
+          }
+          float ov[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool ok = gx + r < p.GW;
+            const float yv = fmaf(ea, sv[r], eb);
+            const float gyv = (ok && yv > 0.f) ? acc[m][nt][r] : 0.f;
+            const float xh = (sv[r] - emean) * einv;
+            s1 += gyv;
+            s2 += gyv * xh;
+            ov[r] = fmaf(egam, gyv, gv[r]);
+          }
+          if (vec) {
+            *reinterpret_cast<float4*>(gp) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (gx + r < p.GW) gp[r] = ov[r];
+          }
+        }
+      }
+      s1 = group4_sum(s1);
+      s2 = group4_sum(s2);
+      if (lk == 0) {
+        red[((wave * NT + nt) * 16 + lj) * 2 + 0] = s1;
+        red[((wave * NT + nt) * 16 + lj) * 2 + 1] = s2;
+      }
+    }
+    __syncthreads();
+    if (p.stat_partial != nullptr && tid < NT * 16) {
+      const int j = jbase + tid;
+      if (j < p.J) {
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          a1 += red[((w * NT) * 16 + tid) * 2 + 0];
+          a2 += red[((w * NT) * 16 + tid) * 2 + 1];
+        }
+        p.stat_partial[(blk_lin * p.J + j) * 2 + 0] = a1;
+        p.stat_partial[(blk_lin * p.J + j) * 2 + 1] = a2;
+      }
+    }
+  } else {  // EPI_POOL: conv output tile -> LDS -> 2x2 max (first max wins) -> pooled store + argmax index
+    static_assert(EPI != EPI_POOL || (TH * TW == 256), "pool epilogue assumes 64 pooled pixels per channel");
+    constexpr int PH = TH / 2, PW = TW / 2;
+    float* ol = smem;
+    const int oy0 = gy0 >> 1, ox0 = gx0 >> 1;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      __syncthreads();
+      {
+        const int j = jbase + nt * 16 + lj;
+        float bias_j = 0.f, sc = 1.f;
+        if (j < p.J) {
+          if (p.bias) bias_j = p.bias[j];
+          if (p.nscale) sc = p.nscale[(long long)n * p.J + j];
+        }
+#pragma unroll
+        for (int m = 0; m < MPW; ++m) {
+          const int q = (wave * MPW + m) * 16 + lk * 4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ol[lj * C::OLS + q + r] = (acc[m][nt][r] + bias_j) * sc;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int e = tid + 256 * i;
+        const int chl = e / (PH * PW);  // == wave + 4*i : wave-uniform
+        const int rem = e - chl * (PH * PW);
+        const int pyy = rem / PW, pxx = rem - pyy * PW;
+        const int jo = jbase + nt * 16 + chl;
+        const int oy = oy0 + pyy, ox = ox0 + pxx;
+        const bool valid = (jo < p.J) && (oy < p.Hout) && (ox < p.Wout);
+        const int base = chl * C::OLS + (2 * pyy) * TW + 2 * pxx;
+        const float v00 = ol[base], v01 = ol[base + 1], v10 = ol[base + TW], v11 = ol[base + TW + 1];
+        float best = v00;
+        int bi = 0;
+        if (v01 > best) { best = v01; bi = 1; }
+        if (v10 > best) { best = v10; bi = 2; }
+        if (v11 > best) { best = v11; bi = 3; }
+        if (valid) {
+          p.out[(long long)n * p.out_ns + (long long)jo * p.out_cs + (long long)oy * p.Wout + ox] = best;
+          p.pool_idx[(((long long)n * p.J + jo) * p.Hout + oy) * p.Wout + ox] = (unsigned char)bi;
+        }
+        float a1 = valid ? best : 0.f;
+        float a2 = valid ? best * best : 0.f;
+        a1 = wave_sum64(a1);
+        a2 = wave_sum64(a2);
+        if (lane == 0 && p.stat_partial != nullptr && jo < p.J) {
+          p.stat_partial[(blk_lin * p.J + jo) * 2 + 0] = a1;
+          p.stat_partial[(blk_lin * p.J + jo) * 2 + 1] = a2;
+        }
+      }
+    }
+  }
+}
+
+template <int KS, int NT, int PRO, int EPI, int TH, int TW>
+static int launch_t(const IgemmParams& p, int N, hipStream_t stream) {
+  using C = IgCfg<KS, NT, PRO, EPI, TH, TW>;
+  static bool attr_done = false;
+  auto kern = igemm_k<KS, NT, PRO, EPI, TH, TW>;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              C::LDS_BYTES);
+    (void)hipGetLastError();
+    attr_done = true;
+  }
+  dim3 grid((unsigned)(p.ncls * p.tiles_x * p.tiles_y), (unsigned)((p.J + NT * 16 - 1) / (NT * 16)), (unsigned)N);
+  hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, stream, p);
+  return (int)hipGetLastError();
+}
+
+void igemm_tile_dims(IgemmKind kind, int tile, int* th, int* tw) {
+  if (kind == IG_S2D3) {
+    *th = 8;
+    *tw = 16;
+  } else if (tile == 0) {
+    *th = 8;
+    *tw = 32;
+  } else {
+    *th = 16;
+    *tw = 16;
+  }
+}
+
+int igemm_pick_tile(int gh, int gw) {
+  // covered area of each tiling; prefer the one wasting fewer pixels (ties -> 8x32: longer rows)
+  const long long a0 = (long long)((gh + 7) / 8) * ((gw + 31) / 32);
+  const long long a1 = (long long)((gh + 15) / 16) * ((gw + 15) / 16);
+  return (a1 < a0) ? 1 : 0;
+}
+
+int igemm_launch(IgemmKind kind, int tile, const IgemmParams& p, int N, hipStream_t stream) {
+  switch (kind) {
+    case IG_CONV3_BN:
+      return tile == 0 ? launch_t<3, 1, PRO_BNRELU, EPI_STORE, 8, 32>(p, N, stream)
+                       : launch_t<3, 1, PRO_BNRELU, EPI_STORE, 16, 16>(p, N, stream);
+    case IG_CONV3_RAW:
+      return tile == 0 ? launch_t<3, 1, PRO_RAW, EPI_STORE, 8, 32>(p, N, stream)
+                       : launch_t<3, 1, PRO_RAW, EPI_STORE, 16, 16>(p, N, stream);
+    case IG_CONV1_POOL:
+      return tile == 0 ? launch_t<1, 4, PRO_BNRELU, EPI_POOL, 8, 32>(p, N, stream)
+                       : launch_t<1, 4, PRO_BNRELU, EPI_POOL, 16, 16>(p, N, stream);
+    case IG_CONV1_BN:
+      return tile == 0 ? launch_t<1, 4, PRO_BNRELU, EPI_STORE, 8, 32>(p, N, stream)
+                       : launch_t<1, 4, PRO_BNRELU, EPI_STORE, 16, 16>(p, N, stream);
+    case IG_DGRAD3:
+      return tile == 0 ? launch_t<3, 4, PRO_RAW, EPI_DGRAD, 8, 32>(p, N, stream)
+                       : launch_t<3, 4, PRO_RAW, EPI_DGRAD, 16, 16>(p, N, stream);
+    case IG_DGRAD1:
+      return tile == 0 ? launch_t<1, 4, PRO_RAW, EPI_DGRAD, 8, 32>(p, N, stream)
+                       : launch_t<1, 4, PRO_RAW, EPI_DGRAD, 16, 16>(p, N, stream);
+    case IG_S2D3:
+      return launch_t<3, 4, PRO_S2D, EPI_STORE, 8, 16>(p, N, stream);
+  }
+  return -1;
+}
+
+// =============================================================================================
+// weight gradients
+// =============================================================================================
+
+template <int KS, int MT, int PRO, bool SHIFT_A, int TH, int TW>
+struct WgCfg {
+  static constexpr bool S2D = (PRO == PRO_S2D);
+  static constexpr int HALO = KS - 1;
+  static constexpr int PITCH = S2D ? (TW + 1) : (TW + HALO);
+  static constexpr int ROWS = S2D ? (TH + 1) : (TH + HALO);
+  static constexpr int PLANE = PITCH * ROWS;
+  static constexpr int POS = PLANE * (S2D ? 4 : 1);
+  static constexpr int NPOS = cdiv(POS, 256);
+  static constexpr int VST = round_mod32(POS, 2);
+  static constexpr int UST = round_mod32(TH * TW, 2);
+  static constexpr int NS = KS * KS;
+  static constexpr int MCH = MT * 16;
+  static constexpr int NCH = 64;
+  static constexpr int VCH = SHIFT_A ? MCH : NCH;
+  static constexpr int UCH = SHIFT_A ? NCH : MCH;
+  static constexpr int V_FLOATS = VCH * VST;
+  static constexpr int U_FLOATS = UCH * UST;
+  static constexpr int LDS_BYTES = (V_FLOATS + U_FLOATS) * 4;
+  __host__ __device__ static constexpr int slot_off(int s) {
+    return S2D ? ((((s / 3) & 1) * 2 + ((s % 3) & 1)) * PLANE + ((s / 3) >> 1) * PITCH + ((s % 3) >> 1))
+               : ((s / KS) * PITCH + (s % KS));
+  }
+};
+
+// dW[m][n][tap] = sum over (sample, pixel) of Mop[m][p] * Nop[n][p (+tap)].
+// Block: MT M-tiles x 4 N-tiles (one per wave); loops over `items_per_chunk` (sample, tile) items,
+// accumulating in registers, then writes one partial slab; a reduce kernel sums the slabs in order.
+template <int KS, int MT, int PRO, bool SHIFT_A, int TH, int TW>
+__global__ __launch_bounds__(256) void wgrad_k(const WgradParams p) {
+  using C = WgCfg<KS, MT, PRO, SHIFT_A, TH, TW>;
+  extern __shared__ __align__(16) float smem[];
+  float* vl = smem;
+  float* ul = smem + C::V_FLOATS;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, lj = lane & 15, lk = lane >> 4;
+  const int chunk = blockIdx.x;
+  const int mbase = blockIdx.y * C::MCH;
+  const int nbase = blockIdx.z * C::NCH;
+  const int ubase = SHIFT_A ? nbase : mbase;
+  const int vbase = SHIFT_A ? mbase : nbase;
+
+  // V staging positions relative to the tile origin
+  int vr[C::NPOS], vc[C::NPOS];
+#pragma unroll
+  for (int i = 0; i < C::NPOS; ++i) {
+    const int e = tid + 256 * i;
+    vr[i] = -100000;
+    vc[i] = 0;
+    if (e < C::POS) {
+      if constexpr (C::S2D) {
+        const int pl = e / C::PLANE, rem = e - pl * C::PLANE;
+        const int r = rem / C::PITCH, col = rem - r * C::PITCH;
+        vr[i] = 2 * r + (pl >> 1);
+        vc[i] = 2 * col + (pl & 1);
+      } else {
+        const int r = e / C::PITCH, col = e - r * C::PITCH;
+        vr[i] = r - C::HALO / 2;
+        vc[i] = col - C::HALO / 2;
+      }
+    }
+  }
+
+  f32x4 acc[MT][C::NS];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int s = 0; s < C::NS; ++s) acc[mt][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int tiles = p.tiles_x * p.tiles_y;
+  const long long total = (long long)p.N * tiles;
+  const long long it0 = (long long)chunk * p.items_per_chunk;
+  long long it1 = it0 + p.items_per_chunk;
+  if (it1 > total) it1 = total;
+
+  for (long long it = it0; it < it1; ++it) {
+    const int n = (int)(it / tiles);
+    const int t = (int)(it - (long long)n * tiles);
+    const int tile_y = t / p.tiles_x, tile_x = t - tile_y * p.tiles_x;
+    const int gy0 = tile_y * TH, gx0 = tile_x * TW;
+    __syncthreads();
+    // ---- U tile (raw, no halo) ----
+    {
+      const float* un = p.u + (long long)n * p.u_ns;
+      for (int e = tid; e < C::UCH * TH * TW; e += 256) {
+        const int cc = e / (TH * TW), q = e - cc * (TH * TW);
+        const int ty = q / TW, tx = q - ty * TW;
+        const int gy = gy0 + ty, gx = gx0 + tx, c = ubase + cc;
+        float v = 0.f;
+        if (c < p.Uc && gy < p.GH && gx < p.GW) v = un[(long long)c * p.u_cs + (long long)gy * p.GW + gx];
+        ul[cc * C::UST + q] = v;
+      }
+    }
+    // ---- V tile (shifted operand) ----
+    {
+      const float* vn = p.v + (long long)n * p.v_ns;
+      const int oy = C::S2D ? 2 * gy0 : gy0, ox = C::S2D ? 2 * gx0 : gx0;
+#pragma unroll 4
+      for (int cc = 0; cc < C::VCH; ++cc) {
+        const int c = vbase + cc;
+        const bool cv = c < p.Vc;
+        const float* src = vn + (long long)c * p.v_cs;
+        float a = 1.f, b = 0.f;
+        if constexpr (PRO == PRO_BNRELU) {
+          if (cv) {
+            a = p.pa[c];
+            b = p.pb[c];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < C::NPOS; ++i) {
+          const int e = tid + 256 * i;
+          if (e < C::POS) {
+            const int iy = oy + vr[i], ix = ox + vc[i];
+            float v = 0.f;
+            if (cv && iy >= 0 && iy < p.Hv && ix >= 0 && ix < p.Wv) {
+              v = src[(long long)iy * p.Wv + ix];
+              if constexpr (PRO == PRO_BNRELU) v = fmaxf(fmaf(a, v, b), 0.f);
+            }
+            vl[cc * C::VST + e] = v;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- MFMA over the tile's pixels, 4 consecutive x per k-step ----
+#pragma unroll 2
+    for (int ks = 0; ks < TH * TW / 4; ++ks) {
+      const int ty = ks / (TW / 4), tx0 = (ks - ty * (TW / 4)) * 4;
+      const int upix = ty * TW + tx0 + lk;
+      const int vpix = ty * C::PITCH + tx0 + lk;
+      if constexpr (!SHIFT_A) {
+        float a[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = ul[(mt * 16 + lj) * C::UST + upix];
+#pragma unroll
+        for (int s = 0; s < C::NS; ++s) {
+          const float b = vl[(wave * 16 + lj) * C::VST + C::slot_off(s) + vpix];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[mt][s] = mfma16(a[mt], b, acc[mt][s]);
+        }
+      } else {
+        const float b = ul[(wave * 16 + lj) * C::UST + upix];
+#pragma unroll
+        for (int s = 0; s < C::NS; ++s) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const float a = vl[(mt * 16 + lj) * C::VST + C::slot_off(s) + vpix];
+            acc[mt][s] = mfma16(a, b, acc[mt][s]);
+          }
+        }
+      }
+    }
+  }
+
+  const int Mc = SHIFT_A ? p.Vc : p.Uc;
+  const int Nc = SHIFT_A ? p.Uc : p.Vc;
+  float* dst = p.partial + (long long)chunk * p.wsize;
+  const int nch = nbase + wave * 16 + lj;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int s = 0; s < C::NS; ++s)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mch = mbase + mt * 16 + 4 * lk + r;
+        if (mch < Mc && nch < Nc) dst[(long long)mch * p.m_stride + (long long)nch * p.n_stride + s] = acc[mt][s][r];
+      }
+}
+
+template <int KS, int MT, int PRO, bool SHIFT_A, int TH, int TW>
+static int wlaunch_t(const WgradParams& p, hipStream_t stream) {
+  using C = WgCfg<KS, MT, PRO, SHIFT_A, TH, TW>;
+  static bool attr_done = false;
+  auto kern = wgrad_k<KS, MT, PRO, SHIFT_A, TH, TW>;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              C::LDS_BYTES);
+    (void)hipGetLastError();
+    attr_done = true;
+  }
+  const int Mc = SHIFT_A ? p.Vc : p.Uc;
+  const int Nc = SHIFT_A ? p.Uc : p.Vc;
+  dim3 grid((unsigned)p.nchunks, (unsigned)((Mc + C::MCH - 1) / C::MCH), (unsigned)((Nc + 63) / 64));
+  hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, stream, p);
+  return (int)hipGetLastError();
+}
+
+void wgrad_tile_dims(WgradKind, int tile, int* th, int* tw) {
+  if (tile == 0) {
+    *th = 4;
+    *tw = 32;
+  } else {
+    *th = 8;
+    *tw = 16;
+  }
+}
+
+int wgrad_pick_tile(int gh, int gw) {
+  const long long a0 = (long long)((gh + 3) / 4) * ((gw + 31) / 32);
+  const long long a1 = (long long)((gh + 7) / 8) * ((gw + 15) / 16);
+  return (a1 < a0) ? 1 : 0;
+}
+
+void wgrad_block_dims(WgradKind kind, int* m_per_block, int* n_per_block) {
+  *m_per_block = (kind == WG_PW1) ? 64 : 16;
+  *n_per_block = 64;
+}
+
+int wgrad_launch(WgradKind kind, int tile, const WgradParams& p, hipStream_t stream) {
+  switch (kind) {
+    case WG_DENSE3:
+      return tile == 0 ? wlaunch_t<3, 1, PRO_BNRELU, false, 4, 32>(p, stream)
+                       : wlaunch_t<3, 1, PRO_BNRELU, false, 8, 16>(p, stream);
+    case WG_RAW3:
+      return tile == 0 ? wlaunch_t<3, 1, PRO_RAW, false, 4, 32>(p, stream)
+                       : wlaunch_t<3, 1, PRO_RAW, false, 8, 16>(p, stream);
+    case WG_PW1:
+      return tile == 0 ? wlaunch_t<1, 4, PRO_BNRELU, false, 4, 32>(p, stream)
+                       : wlaunch_t<1, 4, PRO_BNRELU, false, 8, 16>(p, stream);
+    case WG_CONVT:
+      return tile == 0 ? wlaunch_t<3, 1, PRO_S2D, true, 4, 32>(p, stream)
+                       : wlaunch_t<3, 1, PRO_S2D, true, 8, 16>(p, stream);
+  }
+  return -1;
+}
+
+}  // namespace rln

@@ -1,0 +1,1202 @@
+// Execution plan + C ABI of the lane-segmentation hot path (see include/rln.h).
+//
+// Memory design (MI355X-first, not a translation of the torch graph):
+//   * one channel-stack buffer per resolution level, laid out [convT out | skip stack | up-block new];
+//     the down block works in place on the middle range, the up block on the whole buffer, so the
+//     reference's torch.cat calls (layers.py:33,39,68) never copy anything;
+//   * per-channel batch statistics are produced once by the kernel that writes a channel and shared by
+//     every BatchNorm that later normalises it (they differ only in gamma/beta);
+//   * backward keeps ONE raw gradient stack per level: each BatchNorm consumer adds gamma*gy into it and
+//     its (sum gy, sum gy*xhat) into per-channel accumulators; the mean-subtraction part of the
+//     BatchNorm gradient is applied lazily when the channel's producer runs its own backward.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rln.h"
+#include "igemm.h"
+#include "pointwise.h"
+
+using namespace rln;
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define RLN_TRY(expr)                                                                   \
+  do {                                                                                  \
+    int _e = (expr);                                                                    \
+    if (_e != 0) return fail(_e, "%s failed with %d (%s:%d)", #expr, _e, __FILE__, __LINE__); \
+  } while (0)
+
+namespace {
+
+struct TensorInfo {
+  std::string name;
+  int kind;
+  int64_t offset;
+  int ndim;
+  int64_t shape[4];
+};
+
+struct BNRef {
+  int C = 0;
+  int64_t gamma = -1, beta = -1;  // parameter arena
+  int64_t rmean = -1, rvar = -1;  // running-stat arena
+  int64_t ab = -1;                // folded affine arena (a at ab, b at ab + ab_total)
+};
+struct ConvRef {
+  int64_t w = -1, b = -1;
+  int cin = 0, cout = 0, ks = 0;
+};
+enum OpType { OP_FIRST = 0, OP_DENSE = 1, OP_TD = 2, OP_TU = 3 };
+struct Op {
+  OpType type;
+  int src_level = 0, dst_level = 0;
+  int in_off = 0, cin = 0;
+  int out_off = 0, cout = 0;
+  BNRef bn;
+  ConvRef conv;
+  int64_t drop_ch = -1;  // cumulative channel offset of this op's Dropout2d call (-1: none)
+  int seg = 0;
+  int acc_lo = 0, acc_hi = 0;  // backward: logical input channels that already hold gradient
+  int64_t grad_begin = 0, grad_end = 0;
+};
+struct Level {
+  int C = 0, H = 0, W = 0;
+  int64_t stat_off = 0;  // into per-channel arrays
+  float* S = nullptr;
+  float* G = nullptr;
+};
+
+}  // namespace
+
+struct rln_ctx {
+  rln_config cfg;
+  std::vector<TensorInfo> tensors;
+  std::vector<Op> ops;
+  std::vector<Level> levels;  // n_down resolution levels + bottleneck
+  int64_t n_param = 0, n_bnstat = 0, n_nbt = 0, n_ab = 0, n_chan = 0;
+  int feat_C = 0;
+  std::vector<int> drop_per_call;
+  int64_t drop_total = 0;
+  ConvRef cls;
+  int n_seg = 0;
+  std::vector<int64_t> seg_begin, seg_end;
+  // bound arenas
+  float* params = nullptr;
+  float* grads = nullptr;
+  float* bnrun = nullptr;
+  int64_t* nbt = nullptr;
+  // workspace
+  int N = 0, H = 0, W = 0, with_bwd = 0;
+  float *mean = nullptr, *var = nullptr, *invstd = nullptr, *stdv = nullptr, *S1 = nullptr, *S2 = nullptr;
+  float* ab = nullptr;
+  float* masks = nullptr;
+  float* stat_partial = nullptr;
+  float* dY = nullptr;
+  float* wpartial = nullptr;
+  float* bpartial = nullptr;
+  float* glin = nullptr;
+  unsigned char* pool_idx = nullptr;
+  std::vector<int64_t> pool_off;  // per TD op index in ops
+  LossScratch loss;
+  // forward/backward hand-over state
+  const float* last_x = nullptr;
+  const int64_t* last_y = nullptr;
+  int have_train_fwd = 0, have_loss = 0;
+  const float* last_scales = nullptr;
+};
+
+namespace {
+
+void add_tensor(rln_ctx* c, const std::string& name, int kind, int64_t off, std::initializer_list<int64_t> shp) {
+  TensorInfo t;
+  t.name = name;
+  t.kind = kind;
+  t.offset = off;
+  t.ndim = (int)shp.size();
+  int i = 0;
+  for (auto v : shp) t.shape[i++] = v;
+  for (; i < 4; ++i) t.shape[i] = 1;
+  c->tensors.push_back(t);
+}
+
+BNRef add_bn(rln_ctx* c, const std::string& prefix, int C) {
+  BNRef b;
+  b.C = C;
+  b.gamma = c->n_param;
+  add_tensor(c, prefix + ".weight", RLN_T_PARAM, c->n_param, {C});
+  c->n_param += C;
+  b.beta = c->n_param;
+  add_tensor(c, prefix + ".bias", RLN_T_PARAM, c->n_param, {C});
+  c->n_param += C;
+  b.rmean = c->n_bnstat;
+  add_tensor(c, prefix + ".running_mean", RLN_T_RUNNING_MEAN, c->n_bnstat, {C});
+  c->n_bnstat += C;
+  b.rvar = c->n_bnstat;
+  add_tensor(c, prefix + ".running_var", RLN_T_RUNNING_VAR, c->n_bnstat, {C});
+  c->n_bnstat += C;
+  c->tensors.push_back(TensorInfo{prefix + ".num_batches_tracked", RLN_T_NUM_BATCHES, c->n_nbt, 0, {1, 1, 1, 1}});
+  c->n_nbt += 1;
+  b.ab = c->n_ab;
+  c->n_ab += C;
+  return b;
+}
+
+ConvRef add_conv(rln_ctx* c, const std::string& prefix, int d0, int d1, int ks, int cin, int cout) {
+  ConvRef r;
+  r.cin = cin;
+  r.cout = cout;
+  r.ks = ks;
+  r.w = c->n_param;
+  add_tensor(c, prefix + ".weight", RLN_T_PARAM, c->n_param, {d0, d1, ks, ks});
+  c->n_param += (int64_t)d0 * d1 * ks * ks;
+  r.b = c->n_param;
+  add_tensor(c, prefix + ".bias", RLN_T_PARAM, c->n_param, {cout});
+  c->n_param += cout;
+  return r;
+}
+
+std::string fmt(const char* f, int a, int b = 0) {
+  char buf[160];
+  snprintf(buf, sizeof(buf), f, a, b);
+  return buf;
+}
+
+// Builds ops in forward execution order; the parameter arena follows the same order.
+int build_plan(rln_ctx* c) {
+  const rln_config& g = c->cfg;
+  if (g.n_down < 1 || g.n_down > RLN_MAX_BLOCKS || g.n_up != g.n_down)
+    return fail(RLN_ERR_ARG, "need 1 <= n_down == n_up <= %d", RLN_MAX_BLOCKS);
+  if (g.growth_rate < 1 || g.first_conv_channels < 1 || g.in_channels < 1 || g.n_classes < 1 || g.n_classes > 16 ||
+      g.bottleneck_layers < 1)
+    return fail(RLN_ERR_ARG, "bad channel configuration");
+  const int gr = g.growth_rate, nd = g.n_down;
+  for (int i = 0; i < nd; ++i)
+    if (g.down_blocks[i] < 1 || g.up_blocks[i] < 1) return fail(RLN_ERR_ARG, "blocks need >= 1 layer");
+  // channel bookkeeping (tiramisu.py:26-87)
+  std::vector<int> skip(nd), ct(nd), upnew(nd), down_in(nd);
+  int cur = g.first_conv_channels;
+  for (int i = 0; i < nd; ++i) {
+    down_in[i] = cur;
+    cur += gr * g.down_blocks[i];
+    skip[i] = cur;
+  }
+  const int bott_in = cur, bott_new = gr * g.bottleneck_layers;
+  int prev = bott_new;
+  for (int i = 0; i < nd; ++i) {
+    const int L = nd - 1 - i;
+    ct[L] = prev;
+    upnew[L] = gr * g.up_blocks[i];
+    prev = upnew[L];
+  }
+  c->levels.resize(nd + 1);
+  int64_t so = 0;
+  for (int L = 0; L < nd; ++L) {
+    c->levels[L].C = ct[L] + skip[L] + upnew[L];
+    c->levels[L].stat_off = so;
+    so += c->levels[L].C;
+  }
+  c->levels[nd].C = bott_in + bott_new;
+  c->levels[nd].stat_off = so;
+  so += c->levels[nd].C;
+  c->n_chan = so;
+  c->feat_C = c->levels[0].C;
+
+  const std::string fe = "featureExtractor.";
+  int seg_of_down_stage0 = 0;
+  (void)seg_of_down_stage0;
+  // segments in BACKWARD order: 0 = head, 1..nd = up stages (level 0 first), nd+1 = bottleneck,
+  // nd+2 .. 2nd+1 = down stages (deepest first), 2nd+2 = first conv
+  c->n_seg = 2 * nd + 3;
+  auto seg_up = [&](int i /*up stage index, forward order*/) { return 1 + (nd - 1 - i); };
+  auto seg_down = [&](int i) { return nd + 2 + (nd - 1 - i); };
+  int64_t drop_ch = 0;
+
+  {  // first conv (tiramisu.py:33-35)
+    Op o;
+    o.type = OP_FIRST;
+    o.src_level = -1;
+    o.dst_level = 0;
+    o.cin = g.in_channels;
+    o.out_off = ct[0];
+    o.cout = g.first_conv_channels;
+    o.grad_begin = c->n_param;
+    o.conv = add_conv(c, fe + "firstconv", o.cout, o.cin, 3, o.cin, o.cout);
+    o.grad_end = c->n_param;
+    o.seg = 2 * nd + 2;
+    c->ops.push_back(o);
+  }
+  auto add_dense = [&](const std::string& prefix, int level, int in_off, int cin, int seg) {
+    Op o;
+    o.type = OP_DENSE;
+    o.src_level = o.dst_level = level;
+    o.in_off = in_off;
+    o.cin = cin;
+    o.out_off = in_off + cin;
+    o.cout = gr;
+    o.grad_begin = c->n_param;
+    o.bn = add_bn(c, prefix + ".norm", cin);
+    o.conv = add_conv(c, prefix + ".conv", gr, cin, 3, cin, gr);
+    o.grad_end = c->n_param;
+    o.drop_ch = drop_ch;
+    drop_ch += gr;
+    c->drop_per_call.push_back(gr);
+    o.seg = seg;
+    c->ops.push_back(o);
+  };
+  for (int i = 0; i < nd; ++i) {  // down path (tiramisu.py:41-49)
+    for (int j = 0; j < g.down_blocks[i]; ++j)
+      add_dense(fe + fmt("denseBlocksDown.%d.layers.%d", i, j), i, ct[i], down_in[i] + j * gr, seg_down(i));
+    Op o;
+    o.type = OP_TD;
+    o.src_level = i;
+    o.dst_level = i + 1;
+    o.in_off = ct[i];
+    o.cin = skip[i];
+    o.out_off = (i + 1 < nd) ? ct[i + 1] : 0;
+    o.cout = skip[i];
+    o.grad_begin = c->n_param;
+    o.bn = add_bn(c, fe + fmt("transDownBlocks.%d.norm", i), skip[i]);
+    o.conv = add_conv(c, fe + fmt("transDownBlocks.%d.conv", i), skip[i], skip[i], 1, skip[i], skip[i]);
+    o.grad_end = c->n_param;
+    o.drop_ch = drop_ch;
+    drop_ch += skip[i];
+    c->drop_per_call.push_back(skip[i]);
+    o.seg = seg_down(i);
+    c->ops.push_back(o);
+  }
+  for (int j = 0; j < g.bottleneck_layers; ++j)  // bottleneck (tiramisu.py:55-58)
+    add_dense(fe + fmt("bottleneck.bottleneck.layers.%d", j), nd, 0, bott_in + j * gr, nd + 1);
+  for (int i = 0; i < nd; ++i) {  // up path (tiramisu.py:64-85)
+    const int L = nd - 1 - i;
+    Op o;
+    o.type = OP_TU;
+    o.src_level = L + 1;
+    o.dst_level = L;
+    o.cin = ct[L];
+    o.cout = ct[L];
+    if (L + 1 == nd) {
+      o.in_off = bott_in;
+    } else {
+      o.in_off = ct[L + 1] + skip[L + 1];
+    }
+    o.out_off = 0;
+    o.grad_begin = c->n_param;
+    o.conv = add_conv(c, fe + fmt("transUpBlocks.%d.convTrans", i), ct[L], ct[L], 3, ct[L], ct[L]);
+    o.grad_end = c->n_param;
+    o.seg = seg_up(i);
+    c->ops.push_back(o);
+    for (int j = 0; j < g.up_blocks[i]; ++j)
+      add_dense(fe + fmt("denseBlocksUp.%d.layers.%d", i, j), L, 0, ct[L] + skip[L] + j * gr, seg_up(i));
+  }
+  c->drop_total = drop_ch;
+  {  // classifier (tiramisu.py:112-118)
+    c->cls.cin = c->feat_C;
+    c->cls.cout = g.n_classes;
+    c->cls.ks = 1;
+    c->cls.w = c->n_param;
+    add_tensor(c, "classifier.finalConv.weight", RLN_T_PARAM, c->n_param, {g.n_classes, c->feat_C, 1, 1});
+    c->n_param += (int64_t)g.n_classes * c->feat_C;
+    c->cls.b = c->n_param;
+    add_tensor(c, "classifier.finalConv.bias", RLN_T_PARAM, c->n_param, {g.n_classes});
+    c->n_param += g.n_classes;
+  }
+  // segment gradient ranges (contiguous by construction: arena order == execution order)
+  c->seg_begin.assign(c->n_seg, INT64_MAX);
+  c->seg_end.assign(c->n_seg, -1);
+  for (const Op& o : c->ops) {
+    if (o.grad_begin < c->seg_begin[o.seg]) c->seg_begin[o.seg] = o.grad_begin;
+    if (o.grad_end > c->seg_end[o.seg]) c->seg_end[o.seg] = o.grad_end;
+  }
+  c->seg_begin[0] = c->cls.w;
+  c->seg_end[0] = c->n_param;
+
+  // backward accumulate-vs-overwrite ranges: simulate which gradient channels are initialised
+  std::vector<std::vector<char>> init(nd + 1);
+  for (int L = 0; L <= nd; ++L) init[L].assign(c->levels[L].C, 0);
+  std::fill(init[0].begin(), init[0].end(), 1);  // head backward writes every level-0 channel
+  for (int k = (int)c->ops.size() - 1; k >= 0; --k) {
+    Op& o = c->ops[k];
+    if (o.type == OP_TU) {
+      for (int ch = 0; ch < o.cin; ++ch) init[o.src_level][o.in_off + ch] = 1;
+    } else if (o.type == OP_DENSE || o.type == OP_TD) {
+      std::vector<char>& v = init[o.src_level];
+      int lo = -1, hi = -1;
+      bool contiguous = true;
+      for (int ch = 0; ch < o.cin; ++ch) {
+        if (v[o.in_off + ch]) {
+          if (lo < 0) lo = ch;
+          if (hi >= 0 && ch != hi) contiguous = false;
+          hi = ch + 1;
+        }
+      }
+      if (!contiguous) return fail(RLN_ERR_UNSUPPORTED, "non-contiguous gradient initialisation in op %d", k);
+      o.acc_lo = lo < 0 ? 0 : lo;
+      o.acc_hi = lo < 0 ? 0 : hi;
+      for (int ch = 0; ch < o.cin; ++ch) v[o.in_off + ch] = 1;
+    }
+  }
+  return 0;
+}
+
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* b) : base((char*)b) {}
+  template <typename T>
+  T* take(size_t count) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = base ? (T*)(base + off) : nullptr;
+    off += count * sizeof(T);
+    return p;
+  }
+};
+
+void level_dims(const rln_ctx* c, int h, int w, std::vector<int>& hs, std::vector<int>& ws) {
+  const int nd = c->cfg.n_down;
+  hs.resize(nd + 1);
+  ws.resize(nd + 1);
+  hs[0] = h;
+  ws[0] = w;
+  for (int L = 1; L <= nd; ++L) {
+    hs[L] = hs[L - 1] / 2;
+    ws[L] = ws[L - 1] / 2;
+  }
+}
+
+long long wgrad_chunks(long long total_items, int mgroups, int ngroups, int* ipc) {
+  long long want = (1024 + (long long)mgroups * ngroups - 1) / ((long long)mgroups * ngroups);
+  if (want < 1) want = 1;
+  if (want > total_items) want = total_items;
+  long long per = (total_items + want - 1) / want;
+  *ipc = (int)per;
+  return (total_items + per - 1) / per;
+}
+
+// Lays out (or just sizes, when base == nullptr) the workspace for geometry (n,h,w).
+size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool assign) {
+  const int nd = c->cfg.n_down;
+  std::vector<int> hs, ws;
+  level_dims(c, h, w, hs, ws);
+  Carver cv(base);
+  std::vector<float*> S(nd + 1), G(nd + 1);
+  for (int L = 0; L <= nd; ++L) S[L] = cv.take<float>((size_t)n * c->levels[L].C * hs[L] * ws[L]);
+  for (int L = 0; L <= nd; ++L) G[L] = with_bwd ? cv.take<float>((size_t)n * c->levels[L].C * hs[L] * ws[L]) : nullptr;
+  float* mean = cv.take<float>(c->n_chan);
+  float* var = cv.take<float>(c->n_chan);
+  float* invstd = cv.take<float>(c->n_chan);
+  float* stdv = cv.take<float>(c->n_chan);
+  float* S12 = cv.take<float>(2 * c->n_chan);
+  float* ab = cv.take<float>(2 * c->n_ab);
+  float* masks = cv.take<float>((size_t)n * c->drop_total);
+  // scratch maxima
+  size_t stat_max = 0, dy_max = 0, wp_max = 0, bp_max = 0, pool_bytes = 0;
+  std::vector<int64_t> pool_off(c->ops.size(), -1);
+  for (size_t k = 0; k < c->ops.size(); ++k) {
+    const Op& o = c->ops[k];
+    const int Hd = hs[o.dst_level], Wd = ws[o.dst_level];
+    if (o.type == OP_FIRST || o.type == OP_DENSE) {
+      int th, tw;
+      const int tile = igemm_pick_tile(Hd, Wd);
+      igemm_tile_dims(IG_CONV3_BN, tile, &th, &tw);
+      const size_t blocks = (size_t)n * ((Hd + th - 1) / th) * ((Wd + tw - 1) / tw);
+      stat_max = std::max(stat_max, blocks * o.cout * 2);
+      if (with_bwd) {
+        stat_max = std::max(stat_max, blocks * o.cin * 2);
+        dy_max = std::max(dy_max, (size_t)n * o.cout * Hd * Wd);
+        bp_max = std::max(bp_max, (size_t)grad_finalize_rows(n, Hd, Wd) * o.cout);
+        int wth, wtw, ipc;
+        wgrad_tile_dims(WG_DENSE3, wgrad_pick_tile(Hd, Wd), &wth, &wtw);
+        const long long items = (long long)n * ((Hd + wth - 1) / wth) * ((Wd + wtw - 1) / wtw);
+        const long long nch = wgrad_chunks(items, (o.cout + 15) / 16, (o.cin + 63) / 64, &ipc);
+        wp_max = std::max(wp_max, (size_t)nch * o.cout * o.cin * 9);
+      }
+    } else if (o.type == OP_TD) {
+      const int Hs = hs[o.src_level], Ws = ws[o.src_level];
+      int th, tw;
+      const int tile = igemm_pick_tile(Hs, Ws);
+      igemm_tile_dims(IG_CONV1_POOL, tile, &th, &tw);
+      const size_t blocks = (size_t)n * ((Hs + th - 1) / th) * ((Ws + tw - 1) / tw);
+      stat_max = std::max(stat_max, blocks * o.cout * 2);
+      pool_off[k] = (int64_t)pool_bytes;
+      pool_bytes += (size_t)n * o.cout * Hd * Wd;
+      pool_bytes = (pool_bytes + 255) & ~(size_t)255;
+      if (with_bwd) {
+        dy_max = std::max(dy_max, (size_t)n * o.cout * Hs * Ws);
+        bp_max = std::max(bp_max, (size_t)grad_finalize_rows(n, Hs, Ws) * o.cout);
+        int wth, wtw, ipc;
+        wgrad_tile_dims(WG_PW1, wgrad_pick_tile(Hs, Ws), &wth, &wtw);
+        const long long items = (long long)n * ((Hs + wth - 1) / wth) * ((Ws + wtw - 1) / wtw);
+        const long long nch = wgrad_chunks(items, (o.cout + 63) / 64, (o.cin + 63) / 64, &ipc);
+        wp_max = std::max(wp_max, (size_t)nch * o.cout * o.cin);
+      }
+    } else {  // OP_TU
+      const int GHc = (Hd + 1) / 2, GWc = (Wd + 1) / 2;
+      int th, tw;
+      const int tile = igemm_pick_tile(GHc, GWc);
+      igemm_tile_dims(IG_CONV3_RAW, tile, &th, &tw);
+      const size_t blocks = (size_t)n * 4 * ((GHc + th - 1) / th) * ((GWc + tw - 1) / tw);
+      stat_max = std::max(stat_max, blocks * o.cout * 2);
+      if (with_bwd) {
+        const int Hs = hs[o.src_level], Ws = ws[o.src_level];
+        dy_max = std::max(dy_max, (size_t)n * o.cout * Hd * Wd);
+        bp_max = std::max(bp_max, (size_t)grad_finalize_rows(n, Hd, Wd) * o.cout);
+        int wth, wtw, ipc;
+        wgrad_tile_dims(WG_CONVT, wgrad_pick_tile(Hs, Ws), &wth, &wtw);
+        const long long items = (long long)n * ((Hs + wth - 1) / wth) * ((Ws + wtw - 1) / wtw);
+        const long long nch = wgrad_chunks(items, (o.cout + 15) / 16, (o.cin + 63) / 64, &ipc);
+        wp_max = std::max(wp_max, (size_t)nch * o.cout * o.cin * 9);
+      }
+    }
+  }
+  const size_t hw0 = (size_t)h * w;
+  if (with_bwd) {
+    bp_max = std::max(bp_max, (size_t)n * ((hw0 + 255) / 256) * c->cfg.n_classes);
+    wp_max = std::max(wp_max, (size_t)n * c->cfg.n_classes * c->feat_C);
+  }
+  float* stat_partial = cv.take<float>(stat_max);
+  unsigned char* pool_idx = cv.take<unsigned char>(pool_bytes);
+  float* dY = with_bwd ? cv.take<float>(dy_max) : nullptr;
+  float* wpartial = with_bwd ? cv.take<float>(wp_max) : nullptr;
+  float* bpartial = with_bwd ? cv.take<float>(bp_max) : nullptr;
+  float* glin = with_bwd ? cv.take<float>((size_t)n * c->cfg.n_classes * hw0) : nullptr;
+  int* lcounts = cv.take<int>(32 + 256);
+  float* lpartial = cv.take<float>((size_t)loss_blocks((long long)n * hw0) * 4);
+  float* lresult = cv.take<float>(64);
+  if (assign) {
+    for (int L = 0; L <= nd; ++L) {
+      c->levels[L].H = hs[L];
+      c->levels[L].W = ws[L];
+      c->levels[L].S = S[L];
+      c->levels[L].G = G[L];
+    }
+    c->mean = mean;
+    c->var = var;
+    c->invstd = invstd;
+    c->stdv = stdv;
+    c->S1 = S12;
+    c->S2 = S12 + c->n_chan;
+    c->ab = ab;
+    c->masks = masks;
+    c->stat_partial = stat_partial;
+    c->pool_idx = pool_idx;
+    c->pool_off = pool_off;
+    c->dY = dY;
+    c->wpartial = wpartial;
+    c->bpartial = bpartial;
+    c->glin = glin;
+    c->loss.counts = lcounts;
+    c->loss.partial = lpartial;
+    c->loss.result = lresult;
+  }
+  return (cv.off + 255) & ~(size_t)255;
+}
+
+inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// ---------------------------------------------------------------------------------------------
+// forward ops
+// ---------------------------------------------------------------------------------------------
+
+int finalize_stats(rln_ctx* c, int level, int ch_off, int J, long long nblk, hipStream_t s) {
+  const Level& lv = c->levels[level];
+  const double count = (double)c->N * lv.H * lv.W;
+  const int64_t so = lv.stat_off + ch_off;
+  RLN_TRY(bn_finalize(c->stat_partial, nblk, J, count, c->cfg.bn_eps, c->mean + so, c->var + so, c->invstd + so,
+                      c->stdv + so, s));
+  return 0;
+}
+
+int prep_bn(rln_ctx* c, const Op& o, int training, hipStream_t s) {
+  const Level& lv = c->levels[o.src_level];
+  const int64_t so = lv.stat_off + o.in_off;
+  const double count = (double)c->N * lv.H * lv.W;
+  RLN_TRY(bn_prep(training, o.bn.C, c->params + o.bn.gamma, c->params + o.bn.beta, c->mean + so, c->var + so,
+                  c->invstd + so, c->bnrun + o.bn.rmean, c->bnrun + o.bn.rvar, c->cfg.bn_momentum, count,
+                  c->cfg.bn_eps, c->ab + o.bn.ab, c->ab + c->n_ab + o.bn.ab, s));
+  return 0;
+}
+
+int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
+  const Op& o = c->ops[k];
+  const int N = c->N;
+  const Level& dl = c->levels[o.dst_level];
+  IgemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.ncls = 1;
+  p.tapmode = TM_ID;
+  p.J = o.cout;
+  p.K = o.cin;
+  p.bias = c->params + o.conv.b;
+  p.nscale = (training && o.drop_ch >= 0) ? (c->masks + (size_t)N * o.drop_ch) : nullptr;
+  p.stat_partial = training ? c->stat_partial : nullptr;
+  p.out = dl.S + (size_t)o.out_off * dl.H * dl.W;
+  p.out_ns = (long long)dl.C * dl.H * dl.W;
+  p.out_cs = dl.H * dl.W;
+  p.Hout = dl.H;
+  p.Wout = dl.W;
+  p.w = c->params + o.conv.w;
+  IgemmKind kind;
+  int tile;
+  if (o.type == OP_FIRST) {
+    kind = IG_CONV3_RAW;
+    p.in = x;
+    p.in_ns = (long long)o.cin * dl.H * dl.W;
+    p.in_cs = dl.H * dl.W;
+    p.Hin = dl.H;
+    p.Win = dl.W;
+    p.w_js = (long long)o.cin * 9;
+    p.w_ks = 9;
+    p.GH = dl.H;
+    p.GW = dl.W;
+  } else if (o.type == OP_DENSE) {
+    kind = IG_CONV3_BN;
+    RLN_TRY(prep_bn(c, o, training, s));
+    p.in = dl.S + (size_t)o.in_off * dl.H * dl.W;
+    p.in_ns = p.out_ns;
+    p.in_cs = p.out_cs;
+    p.Hin = dl.H;
+    p.Win = dl.W;
+    p.pa = c->ab + o.bn.ab;
+    p.pb = c->ab + c->n_ab + o.bn.ab;
+    p.w_js = (long long)o.cin * 9;
+    p.w_ks = 9;
+    p.GH = dl.H;
+    p.GW = dl.W;
+  } else if (o.type == OP_TD) {
+    kind = IG_CONV1_POOL;
+    RLN_TRY(prep_bn(c, o, training, s));
+    const Level& sl = c->levels[o.src_level];
+    p.in = sl.S + (size_t)o.in_off * sl.H * sl.W;
+    p.in_ns = (long long)sl.C * sl.H * sl.W;
+    p.in_cs = sl.H * sl.W;
+    p.Hin = sl.H;
+    p.Win = sl.W;
+    p.pa = c->ab + o.bn.ab;
+    p.pb = c->ab + c->n_ab + o.bn.ab;
+    p.w_js = o.cin;
+    p.w_ks = 1;
+    p.GH = sl.H;
+    p.GW = sl.W;
+    p.pool_idx = c->pool_idx + c->pool_off[k];
+  } else {  // OP_TU: ConvTranspose2d by output parity class
+    kind = IG_CONV3_RAW;
+    const Level& sl = c->levels[o.src_level];
+    p.in = sl.S + (size_t)o.in_off * sl.H * sl.W;
+    p.in_ns = (long long)sl.C * sl.H * sl.W;
+    p.in_cs = sl.H * sl.W;
+    p.Hin = sl.H;
+    p.Win = sl.W;
+    p.w_ks = (long long)o.cout * 9;  // weight[c_in][c_out][ky][kx]
+    p.w_js = 9;
+    p.tapmode = TM_CONVT;
+    p.ncls = 4;
+    p.GH = (dl.H + 1) / 2;
+    p.GW = (dl.W + 1) / 2;
+  }
+  tile = igemm_pick_tile(p.GH, p.GW);
+  int th, tw;
+  igemm_tile_dims(kind, tile, &th, &tw);
+  p.tiles_y = (p.GH + th - 1) / th;
+  p.tiles_x = (p.GW + tw - 1) / tw;
+  p.out_vec = (p.ncls == 1 && (p.Wout % 4) == 0 && aligned16(p.out)) ? 1 : 0;
+  RLN_TRY(igemm_launch(kind, tile, p, N, s));
+  if (training) RLN_TRY(finalize_stats(c, o.dst_level, o.out_off, o.cout, igemm_stat_blocks(p, N), s));
+  return 0;
+}
+
+HeadParams head_params(rln_ctx* c) {
+  const Level& l0 = c->levels[0];
+  HeadParams h;
+  h.S = l0.S;
+  h.ns = (long long)l0.C * l0.H * l0.W;
+  h.C = l0.C;
+  h.HW = l0.H * l0.W;
+  h.ncls = c->cfg.n_classes;
+  h.w = c->params + c->cls.w;
+  h.b = c->params + c->cls.b;
+  h.T = c->cfg.temperature;
+  return h;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward ops
+// ---------------------------------------------------------------------------------------------
+
+int finalize_grad_range(rln_ctx* c, int level, int ch_off, int C, const float* nscale, long long* rows,
+                        hipStream_t s) {
+  const Level& lv = c->levels[level];
+  GradFinParams g;
+  memset(&g, 0, sizeof(g));
+  const size_t plane = (size_t)lv.H * lv.W;
+  g.S = lv.S + ch_off * plane;
+  g.G = lv.G + ch_off * plane;
+  g.ns = (long long)lv.C * plane;
+  g.C = C;
+  g.H = lv.H;
+  g.W = lv.W;
+  const int64_t so = lv.stat_off + ch_off;
+  g.mean = c->mean + so;
+  g.invstd = c->invstd + so;
+  g.S1 = c->S1 + so;
+  g.S2 = c->S2 + so;
+  g.invM = (float)(1.0 / ((double)c->N * plane));
+  g.nscale = nscale;
+  g.dst = c->dY;
+  g.bias_partial = c->bpartial;
+  g.Hd = lv.H;
+  g.Wd = lv.W;
+  RLN_TRY(grad_finalize(g, c->N, rows, s));
+  return 0;
+}
+
+int run_wgrad(rln_ctx* c, WgradKind kind, WgradParams& w, int Mc, int Nc, int64_t grad_off, hipStream_t s) {
+  const int tile = wgrad_pick_tile(w.GH, w.GW);
+  int th, tw, mpb, npb;
+  wgrad_tile_dims(kind, tile, &th, &tw);
+  wgrad_block_dims(kind, &mpb, &npb);
+  w.tiles_y = (w.GH + th - 1) / th;
+  w.tiles_x = (w.GW + tw - 1) / tw;
+  w.N = c->N;
+  const long long items = (long long)c->N * w.tiles_x * w.tiles_y;
+  int ipc;
+  const long long nch = wgrad_chunks(items, (Mc + mpb - 1) / mpb, (Nc + npb - 1) / npb, &ipc);
+  w.items_per_chunk = ipc;
+  w.nchunks = (int)nch;
+  w.partial = c->wpartial;
+  RLN_TRY(wgrad_launch(kind, tile, w, s));
+  RLN_TRY(reduce_rows(c->wpartial, nch, w.wsize, c->grads + grad_off, s));
+  return 0;
+}
+
+int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
+  const Op& o = c->ops[k];
+  const int N = c->N;
+  long long rows = 0;
+  if (o.type == OP_DENSE || o.type == OP_FIRST) {
+    const Level& lv = c->levels[o.dst_level];
+    const size_t plane = (size_t)lv.H * lv.W;
+    const float* nscale = (o.drop_ch >= 0) ? (c->masks + (size_t)N * o.drop_ch) : nullptr;
+    RLN_TRY(finalize_grad_range(c, o.dst_level, o.out_off, o.cout, nscale, &rows, s));
+    RLN_TRY(reduce_rows(c->bpartial, rows, o.cout, c->grads + o.conv.b, s));
+    if (o.type == OP_DENSE) {
+      IgemmParams p;
+      memset(&p, 0, sizeof(p));
+      p.in = c->dY;
+      p.in_ns = (long long)o.cout * plane;
+      p.in_cs = (int)plane;
+      p.Hin = lv.H;
+      p.Win = lv.W;
+      p.K = o.cout;
+      p.w = c->params + o.conv.w;  // W[o][c][tap]: j = c, k = o
+      p.w_ks = (long long)o.cin * 9;
+      p.w_js = 9;
+      p.tapmode = TM_FLIP;
+      p.J = o.cin;
+      p.GH = lv.H;
+      p.GW = lv.W;
+      p.ncls = 1;
+      p.out = lv.G + (size_t)o.in_off * plane;
+      p.out_ns = (long long)lv.C * plane;
+      p.out_cs = (int)plane;
+      p.Hout = lv.H;
+      p.Wout = lv.W;
+      p.S = lv.S + (size_t)o.in_off * plane;
+      p.s_ns = p.out_ns;
+      const int64_t so = lv.stat_off + o.in_off;
+      p.ea = c->ab + o.bn.ab;
+      p.eb = c->ab + c->n_ab + o.bn.ab;
+      p.emean = c->mean + so;
+      p.einvstd = c->invstd + so;
+      p.egamma = c->params + o.bn.gamma;
+      p.acc_lo = o.acc_lo;
+      p.acc_hi = o.acc_hi;
+      p.stat_partial = c->stat_partial;
+      const int tile = igemm_pick_tile(p.GH, p.GW);
+      int th, tw;
+      igemm_tile_dims(IG_DGRAD3, tile, &th, &tw);
+      p.tiles_y = (p.GH + th - 1) / th;
+      p.tiles_x = (p.GW + tw - 1) / tw;
+      p.out_vec = ((lv.W % 4) == 0 && aligned16(p.out) && aligned16(p.S)) ? 1 : 0;
+      RLN_TRY(igemm_launch(IG_DGRAD3, tile, p, N, s));
+      RLN_TRY(bn_bwd_finalize(c->stat_partial, igemm_stat_blocks(p, N), o.cin, c->params + o.bn.gamma,
+                              c->grads + o.bn.gamma, c->grads + o.bn.beta, c->S1 + so, c->S2 + so, s));
+    }
+    WgradParams w;
+    memset(&w, 0, sizeof(w));
+    w.u = c->dY;
+    w.u_ns = (long long)o.cout * plane;
+    w.u_cs = (int)plane;
+    w.Uc = o.cout;
+    w.GH = lv.H;
+    w.GW = lv.W;
+    w.Hv = lv.H;
+    w.Wv = lv.W;
+    w.Vc = o.cin;
+    w.v_cs = (int)plane;
+    w.wsize = (long long)o.cout * o.cin * 9;
+    w.m_stride = (long long)o.cin * 9;
+    w.n_stride = 9;
+    if (o.type == OP_DENSE) {
+      w.v = lv.S + (size_t)o.in_off * plane;
+      w.v_ns = (long long)lv.C * plane;
+      w.pa = c->ab + o.bn.ab;
+      w.pb = c->ab + c->n_ab + o.bn.ab;
+      RLN_TRY(run_wgrad(c, WG_DENSE3, w, o.cout, o.cin, o.conv.w, s));
+    } else {
+      w.v = c->last_x;
+      w.v_ns = (long long)o.cin * plane;
+      RLN_TRY(run_wgrad(c, WG_RAW3, w, o.cout, o.cin, o.conv.w, s));
+    }
+  } else if (o.type == OP_TD) {
+    const Level& sl = c->levels[o.src_level];
+    const Level& dl = c->levels[o.dst_level];
+    const size_t splane = (size_t)sl.H * sl.W, dplane = (size_t)dl.H * dl.W;
+    {  // pooled gradient -> pre-pool map (MaxPool2d backward) with the Dropout2d scale
+      GradFinParams g;
+      memset(&g, 0, sizeof(g));
+      g.S = dl.S + (size_t)o.out_off * dplane;
+      g.G = dl.G + (size_t)o.out_off * dplane;
+      g.ns = (long long)dl.C * dplane;
+      g.C = o.cout;
+      g.H = dl.H;
+      g.W = dl.W;
+      const int64_t so = dl.stat_off + o.out_off;
+      g.mean = c->mean + so;
+      g.invstd = c->invstd + so;
+      g.S1 = c->S1 + so;
+      g.S2 = c->S2 + so;
+      g.invM = (float)(1.0 / ((double)N * dplane));
+      g.nscale = c->masks + (size_t)N * o.drop_ch;
+      g.dst = c->dY;
+      g.bias_partial = c->bpartial;
+      g.pool_idx = c->pool_idx + c->pool_off[k];
+      g.Hd = sl.H;
+      g.Wd = sl.W;
+      RLN_TRY(grad_finalize(g, N, &rows, s));
+      RLN_TRY(reduce_rows(c->bpartial, rows, o.cout, c->grads + o.conv.b, s));
+    }
+    IgemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.in = c->dY;
+    p.in_ns = (long long)o.cout * splane;
+    p.in_cs = (int)splane;
+    p.Hin = sl.H;
+    p.Win = sl.W;
+    p.K = o.cout;
+    p.w = c->params + o.conv.w;  // W[o][c]: j = c, k = o
+    p.w_ks = o.cin;
+    p.w_js = 1;
+    p.tapmode = TM_ID;
+    p.J = o.cin;
+    p.GH = sl.H;
+    p.GW = sl.W;
+    p.ncls = 1;
+    p.out = sl.G + (size_t)o.in_off * splane;
+    p.out_ns = (long long)sl.C * splane;
+    p.out_cs = (int)splane;
+    p.Hout = sl.H;
+    p.Wout = sl.W;
+    p.S = sl.S + (size_t)o.in_off * splane;
+    p.s_ns = p.out_ns;
+    const int64_t so = sl.stat_off + o.in_off;
+    p.ea = c->ab + o.bn.ab;
+    p.eb = c->ab + c->n_ab + o.bn.ab;
+    p.emean = c->mean + so;
+    p.einvstd = c->invstd + so;
+    p.egamma = c->params + o.bn.gamma;
+    p.acc_lo = o.acc_lo;
+    p.acc_hi = o.acc_hi;
+    p.stat_partial = c->stat_partial;
+    const int tile = igemm_pick_tile(p.GH, p.GW);
+    int th, tw;
+    igemm_tile_dims(IG_DGRAD1, tile, &th, &tw);
+    p.tiles_y = (p.GH + th - 1) / th;
+    p.tiles_x = (p.GW + tw - 1) / tw;
+    p.out_vec = ((sl.W % 4) == 0 && aligned16(p.out) && aligned16(p.S)) ? 1 : 0;
+    RLN_TRY(igemm_launch(IG_DGRAD1, tile, p, N, s));
+    RLN_TRY(bn_bwd_finalize(c->stat_partial, igemm_stat_blocks(p, N), o.cin, c->params + o.bn.gamma,
+                            c->grads + o.bn.gamma, c->grads + o.bn.beta, c->S1 + so, c->S2 + so, s));
+    WgradParams w;
+    memset(&w, 0, sizeof(w));
+    w.u = c->dY;
+    w.u_ns = (long long)o.cout * splane;
+    w.u_cs = (int)splane;
+    w.Uc = o.cout;
+    w.GH = sl.H;
+    w.GW = sl.W;
+    w.v = sl.S + (size_t)o.in_off * splane;
+    w.v_ns = (long long)sl.C * splane;
+    w.v_cs = (int)splane;
+    w.Vc = o.cin;
+    w.Hv = sl.H;
+    w.Wv = sl.W;
+    w.pa = c->ab + o.bn.ab;
+    w.pb = c->ab + c->n_ab + o.bn.ab;
+    w.wsize = (long long)o.cout * o.cin;
+    w.m_stride = o.cin;
+    w.n_stride = 1;
+    RLN_TRY(run_wgrad(c, WG_PW1, w, o.cout, o.cin, o.conv.w, s));
+  } else {  // OP_TU
+    const Level& sl = c->levels[o.src_level];
+    const Level& dl = c->levels[o.dst_level];
+    const size_t splane = (size_t)sl.H * sl.W, dplane = (size_t)dl.H * dl.W;
+    RLN_TRY(finalize_grad_range(c, o.dst_level, 0, o.cout, nullptr, &rows, s));
+    RLN_TRY(reduce_rows(c->bpartial, rows, o.cout, c->grads + o.conv.b, s));
+    IgemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.in = c->dY;  // dU [N][cout][H][W]
+    p.in_ns = (long long)o.cout * dplane;
+    p.in_cs = (int)dplane;
+    p.Hin = dl.H;
+    p.Win = dl.W;
+    p.K = o.cout;
+    p.w = c->params + o.conv.w;  // weight[c_in][c_out][tap]: j = c_in, k = c_out
+    p.w_js = (long long)o.cout * 9;
+    p.w_ks = 9;
+    p.tapmode = TM_ID;
+    p.J = o.cin;
+    p.GH = sl.H;
+    p.GW = sl.W;
+    p.ncls = 1;
+    p.out = sl.G + (size_t)o.in_off * splane;
+    p.out_ns = (long long)sl.C * splane;
+    p.out_cs = (int)splane;
+    p.Hout = sl.H;
+    p.Wout = sl.W;
+    p.cscale = c->stdv + sl.stat_off + o.in_off;
+    const int tile = 0;
+    int th, tw;
+    igemm_tile_dims(IG_S2D3, tile, &th, &tw);
+    p.tiles_y = (p.GH + th - 1) / th;
+    p.tiles_x = (p.GW + tw - 1) / tw;
+    p.out_vec = ((sl.W % 4) == 0 && aligned16(p.out)) ? 1 : 0;
+    RLN_TRY(igemm_launch(IG_S2D3, tile, p, N, s));
+    WgradParams w;
+    memset(&w, 0, sizeof(w));
+    w.u = sl.S + (size_t)o.in_off * splane;  // convT input (raw)
+    w.u_ns = (long long)sl.C * splane;
+    w.u_cs = (int)splane;
+    w.Uc = o.cin;
+    w.GH = sl.H;
+    w.GW = sl.W;
+    w.v = c->dY;
+    w.v_ns = (long long)o.cout * dplane;
+    w.v_cs = (int)dplane;
+    w.Vc = o.cout;
+    w.Hv = dl.H;
+    w.Wv = dl.W;
+    w.wsize = (long long)o.cin * o.cout * 9;
+    w.m_stride = 9;                       // m = c_out
+    w.n_stride = (long long)o.cout * 9;   // n = c_in
+    RLN_TRY(run_wgrad(c, WG_CONVT, w, o.cout, o.cin, o.conv.w, s));
+  }
+  return 0;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+
+extern "C" {
+
+const char* rln_last_error(void) { return g_err; }
+int rln_version(void) { return 1; }
+
+int rln_create(const rln_config* cfg, rln_ctx** out) {
+  if (!cfg || !out) return fail(RLN_ERR_ARG, "null argument");
+  rln_ctx* c = new rln_ctx();
+  c->cfg = *cfg;
+  const int e = build_plan(c);
+  if (e != 0) {
+    delete c;
+    return e;
+  }
+  *out = c;
+  return 0;
+}
+
+void rln_destroy(rln_ctx* ctx) { delete ctx; }
+
+int rln_num_tensors(const rln_ctx* c) { return (int)c->tensors.size(); }
+int64_t rln_param_count(const rln_ctx* c) { return c->n_param; }
+int64_t rln_bnstat_count(const rln_ctx* c) { return c->n_bnstat; }
+int64_t rln_nbt_count(const rln_ctx* c) { return c->n_nbt; }
+int rln_feature_channels(const rln_ctx* c) { return c->feat_C; }
+int rln_num_dropouts(const rln_ctx* c) { return (int)c->drop_per_call.size(); }
+int64_t rln_dropout_channels(const rln_ctx* c, int* per_call) {
+  if (per_call)
+    for (size_t i = 0; i < c->drop_per_call.size(); ++i) per_call[i] = c->drop_per_call[i];
+  return c->drop_total;
+}
+
+int rln_tensor_info(const rln_ctx* c, int idx, char* name, int name_cap, int* kind, int64_t* offset, int* ndim,
+                    int64_t shape[4]) {
+  if (idx < 0 || idx >= (int)c->tensors.size()) return fail(RLN_ERR_ARG, "tensor index %d out of range", idx);
+  const TensorInfo& t = c->tensors[idx];
+  if (name && name_cap > 0) {
+    strncpy(name, t.name.c_str(), name_cap - 1);
+    name[name_cap - 1] = 0;
+  }
+  if (kind) *kind = t.kind;
+  if (offset) *offset = t.offset;
+  if (ndim) *ndim = t.ndim;
+  if (shape)
+    for (int i = 0; i < 4; ++i) shape[i] = t.shape[i];
+  return 0;
+}
+
+int rln_bind_params(rln_ctx* c, float* params, float* grads, float* bn_running, int64_t* nbt) {
+  if (!params || !bn_running) return fail(RLN_ERR_ARG, "params and bn_running are required");
+  c->params = params;
+  c->grads = grads;
+  c->bnrun = bn_running;
+  c->nbt = nbt;
+  return 0;
+}
+
+size_t rln_workspace_bytes(const rln_ctx* c, int n, int h, int w, int with_backward) {
+  return carve(const_cast<rln_ctx*>(c), nullptr, n, h, w, with_backward, false);
+}
+
+int rln_set_workspace(rln_ctx* c, void* ws, size_t bytes, int n, int h, int w, int with_backward) {
+  if (n < 1 || h < 1 || w < 1) return fail(RLN_ERR_ARG, "bad geometry %dx%dx%d", n, h, w);
+  if ((h >> c->cfg.n_down) < 1 || (w >> c->cfg.n_down) < 1)
+    return fail(RLN_ERR_ARG, "input %dx%d too small for %d poolings (Output size is too small)", h, w, c->cfg.n_down);
+  const size_t need = carve(c, nullptr, n, h, w, with_backward, false);
+  if (!ws || bytes < need) return fail(RLN_ERR_WORKSPACE, "workspace of %zu bytes needed, got %zu", need, bytes);
+  if (((uintptr_t)ws) & 255) return fail(RLN_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+  carve(c, ws, n, h, w, with_backward, true);
+  c->N = n;
+  c->H = h;
+  c->W = w;
+  c->with_bwd = with_backward;
+  c->have_train_fwd = 0;
+  c->have_loss = 0;
+  return 0;
+}
+
+int rln_forward(rln_ctx* c, const float* x, int n, int h, int w, int training, const float* drop_scales, uint64_t seed,
+                float* probs_out, float* feat_out, int use_softmax, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!c->params) return fail(RLN_ERR_STATE, "rln_bind_params not called");
+  if (n != c->N || h != c->H || w != c->W || !c->levels[0].S)
+    return fail(RLN_ERR_WORKSPACE, "workspace not set for geometry %dx%dx%d", n, h, w);
+  if (!x) return fail(RLN_ERR_ARG, "x is null");
+  if (training) {
+    const size_t cnt = (size_t)n * c->drop_total;
+    if (drop_scales) {
+      hipError_t e = hipMemcpyAsync(c->masks, drop_scales, cnt * sizeof(float), hipMemcpyDeviceToDevice, s);
+      if (e != hipSuccess) return fail((int)e, "mask copy failed");
+    } else {
+      RLN_TRY(dropout_scales(c->masks, (long long)cnt, 1.0f - c->cfg.drop_p, (unsigned long long)seed, s));
+    }
+    if (c->nbt) RLN_TRY(add_one_i64((long long*)c->nbt, c->n_nbt, s));
+  }
+  for (size_t k = 0; k < c->ops.size(); ++k) RLN_TRY(fwd_op(c, k, x, training, s));
+  if (probs_out || feat_out) {
+    HeadParams hp = head_params(c);
+    RLN_TRY(head_forward(hp, n, probs_out, use_softmax, feat_out, s));
+  }
+  c->last_x = x;
+  c->have_train_fwd = training ? 1 : 0;
+  c->have_loss = 0;
+  return 0;
+}
+
+int rln_classifier_forward(rln_ctx* c, const float* feat, int n, int h, int w, float* out, int use_softmax,
+                           void* stream) {
+  if (!c->params) return fail(RLN_ERR_STATE, "rln_bind_params not called");
+  HeadParams hp;
+  hp.S = feat;
+  hp.C = c->feat_C;
+  hp.HW = h * w;
+  hp.ns = (long long)hp.C * hp.HW;
+  hp.ncls = c->cfg.n_classes;
+  hp.w = c->params + c->cls.w;
+  hp.b = c->params + c->cls.b;
+  hp.T = c->cfg.temperature;
+  RLN_TRY(classifier_forward(hp, n, out, use_softmax, (hipStream_t)stream));
+  return 0;
+}
+
+int rln_loss(rln_ctx* c, const float* probs, const int64_t* y, int n, int h, int w, int weighted, float* out,
+             int64_t* argmax_out, int64_t* confusion_out, void* stream) {
+  if (!c->loss.counts || n != c->N || h != c->H || w != c->W)
+    return fail(RLN_ERR_WORKSPACE, "workspace not set for geometry %dx%dx%d", n, h, w);
+  RLN_TRY(loss_forward(probs, (const long long*)y, n, c->cfg.n_classes, h * w, weighted, c->loss, out,
+                       (long long*)argmax_out, (long long*)confusion_out, (hipStream_t)stream));
+  c->last_y = y;
+  c->have_loss = weighted ? 1 : 0;
+  return 0;
+}
+
+int rln_backward_segments(const rln_ctx* c) { return c->n_seg; }
+
+int rln_backward_segment_range(const rln_ctx* c, int seg, int64_t* b, int64_t* e) {
+  if (seg < 0 || seg >= c->n_seg) return fail(RLN_ERR_ARG, "segment %d out of range", seg);
+  if (b) *b = c->seg_begin[seg];
+  if (e) *e = c->seg_end[seg];
+  return 0;
+}
+
+int rln_backward(rln_ctx* c, float loss_scale, int seg_begin, int seg_end, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!c->with_bwd || !c->grads) return fail(RLN_ERR_STATE, "no gradient arena / backward workspace");
+  if (!c->have_train_fwd || !c->have_loss)
+    return fail(RLN_ERR_STATE, "rln_backward needs a training rln_forward followed by a weighted rln_loss");
+  if (seg_begin < 0 || seg_end > c->n_seg || seg_begin >= seg_end) return fail(RLN_ERR_ARG, "bad segment range");
+  const int N = c->N;
+  if (seg_begin == 0) {
+    hipError_t e = hipMemsetAsync(c->S1, 0, sizeof(float) * 2 * c->n_chan, s);
+    if (e != hipSuccess) return fail((int)e, "memset failed");
+    HeadBwdParams q;
+    q.h = head_params(c);
+    q.y = (const long long*)c->last_y;
+    q.lossres = c->loss.result;
+    q.loss_scale = loss_scale;
+    q.G = c->levels[0].G;
+    q.g_ns = q.h.ns;
+    q.invstd = c->invstd + c->levels[0].stat_off;
+    q.glin = c->glin;
+    q.bias_partial = c->bpartial;
+    long long rows = 0;
+    RLN_TRY(head_backward_data(q, N, &rows, s));
+    RLN_TRY(reduce_rows(c->bpartial, rows, c->cfg.n_classes, c->grads + c->cls.b, s));
+    RLN_TRY(head_backward_weight(q.h, N, c->glin, c->wpartial, s));
+    RLN_TRY(reduce_rows(c->wpartial, N, (long long)c->cfg.n_classes * c->feat_C, c->grads + c->cls.w, s));
+  }
+  for (int seg = std::max(seg_begin, 1); seg < seg_end; ++seg) {
+    for (int k = (int)c->ops.size() - 1; k >= 0; --k)
+      if (c->ops[k].seg == seg) RLN_TRY(bwd_op(c, (size_t)k, s));
+  }
+  return 0;
+}
+
+int rln_op_conv_bnrelu(const float* x, int n, int cin, int x_ctot, int x_coff, int h, int w, const float* a,
+                       const float* b, const float* weight, const float* bias, int cout, int ksize,
+                       const float* scale, float* out, int out_ctot, int out_coff, int pool, uint8_t* pool_idx,
+                       float* stats, void* workspace, size_t workspace_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (ksize != 1 && ksize != 3) return fail(RLN_ERR_ARG, "ksize must be 1 or 3");
+  if (pool && ksize != 1) return fail(RLN_ERR_UNSUPPORTED, "pool epilogue exists for the 1x1 transition only");
+  if (ksize == 1 && !a) return fail(RLN_ERR_UNSUPPORTED, "1x1 variant needs the folded affine");
+  IgemmParams p;
+  memset(&p, 0, sizeof(p));
+  const size_t plane = (size_t)h * w;
+  p.in = x + (size_t)x_coff * plane;
+  p.in_ns = (long long)x_ctot * plane;
+  p.in_cs = (int)plane;
+  p.Hin = h;
+  p.Win = w;
+  p.K = cin;
+  p.pa = a;
+  p.pb = b;
+  p.w = weight;
+  p.w_js = (long long)cin * ksize * ksize;
+  p.w_ks = ksize * ksize;
+  p.tapmode = TM_ID;
+  p.J = cout;
+  p.GH = h;
+  p.GW = w;
+  p.ncls = 1;
+  const int ho = pool ? h / 2 : h, wo = pool ? w / 2 : w;
+  p.out = out + (size_t)out_coff * ho * wo;
+  p.out_ns = (long long)out_ctot * ho * wo;
+  p.out_cs = ho * wo;
+  p.Hout = ho;
+  p.Wout = wo;
+  p.bias = bias;
+  p.nscale = scale;
+  p.pool_idx = pool_idx;
+  IgemmKind kind = (ksize == 3) ? (a ? IG_CONV3_BN : IG_CONV3_RAW) : (pool ? IG_CONV1_POOL : IG_CONV1_BN);
+  const int tile = igemm_pick_tile(h, w);
+  int th, tw;
+  igemm_tile_dims(kind, tile, &th, &tw);
+  p.tiles_y = (h + th - 1) / th;
+  p.tiles_x = (w + tw - 1) / tw;
+  p.out_vec = (!pool && (wo % 4) == 0 && aligned16(p.out)) ? 1 : 0;
+  const long long nblk = igemm_stat_blocks(p, n);
+  if (stats) {
+    if (!workspace || workspace_bytes < (size_t)nblk * cout * 2 * sizeof(float))
+      return fail(RLN_ERR_WORKSPACE, "stats need %lld bytes of workspace", nblk * cout * 2 * (long long)sizeof(float));
+    p.stat_partial = (float*)workspace;
+  }
+  RLN_TRY(igemm_launch(kind, tile, p, n, s));
+  if (stats) RLN_TRY(reduce_rows(p.stat_partial, nblk, (long long)cout * 2, stats, s));
+  return 0;
+}
+
+int rln_op_convt(const float* x, int n, int cin, int h, int w, const float* weight, const float* bias, int cout,
+                 float* out, int out_ctot, int out_coff, int hout, int wout, void* stream) {
+  if (hout > 2 * h + 1 || wout > 2 * w + 1) return fail(RLN_ERR_ARG, "crop larger than the transposed conv output");
+  IgemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.in = x;
+  p.in_ns = (long long)cin * h * w;
+  p.in_cs = h * w;
+  p.Hin = h;
+  p.Win = w;
+  p.K = cin;
+  p.w = weight;
+  p.w_ks = (long long)cout * 9;
+  p.w_js = 9;
+  p.tapmode = TM_CONVT;
+  p.ncls = 4;
+  p.J = cout;
+  p.GH = (hout + 1) / 2;
+  p.GW = (wout + 1) / 2;
+  p.out = out + (size_t)out_coff * hout * wout;
+  p.out_ns = (long long)out_ctot * hout * wout;
+  p.out_cs = hout * wout;
+  p.Hout = hout;
+  p.Wout = wout;
+  p.bias = bias;
+  const int tile = igemm_pick_tile(p.GH, p.GW);
+  int th, tw;
+  igemm_tile_dims(IG_CONV3_RAW, tile, &th, &tw);
+  p.tiles_y = (p.GH + th - 1) / th;
+  p.tiles_x = (p.GW + tw - 1) / tw;
+  RLN_TRY(igemm_launch(IG_CONV3_RAW, tile, p, n, (hipStream_t)stream));
+  return 0;
+}
+
+int rln_op_classifier(const float* feat, int n, int c, int hw, const float* w, const float* b, int ncls, float T,
+                      float* out, int use_softmax, void* stream) {
+  HeadParams hp;
+  hp.S = feat;
+  hp.C = c;
+  hp.HW = hw;
+  hp.ns = (long long)c * hw;
+  hp.ncls = ncls;
+  hp.w = w;
+  hp.b = b;
+  hp.T = T;
+  RLN_TRY(classifier_forward(hp, n, out, use_softmax, (hipStream_t)stream));
+  return 0;
+}
+
+int rln_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t count, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                   void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || count < 0 || step < 1) return fail(RLN_ERR_ARG, "bad argument");
+  RLN_TRY(adamw(params, grads, exp_avg, exp_avg_sq, count, lr, beta1, beta2, eps, weight_decay, step, grad_scale,
+                (hipStream_t)stream));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,91 @@
+// HBM-bound kernels of the path: BatchNorm statistics / affine folding, gradient finalisation,
+// head (normalize + classifier + softmax), loss, AdamW, dropout masks.
+#pragma once
+#include "common.h"
+
+namespace rln {
+
+// ---- BatchNorm bookkeeping -----------------------------------------------------------------
+// partial: [nblk][J][2] (sum, sum of squares) written by a producing kernel; finalises
+// mean / biased var / invstd for J channels into level arrays at channel offset.
+int bn_finalize(const float* partial, long long nblk, int J, double count, float eps, float* mean, float* var,
+                float* invstd, float* stdv, hipStream_t s);
+// folds a BatchNorm2d into per-channel (a, b): train -> batch stats (+ running-stat update, momentum,
+// unbiased var); eval -> running stats.
+int bn_prep(int training, int C, const float* gamma, const float* beta, const float* mean, const float* var,
+            const float* invstd, float* running_mean, float* running_var, float momentum, double count, float eps,
+            float* a, float* b, hipStream_t s);
+// backward: reduces [nblk][J][2] partials (sum gy, sum gy*xhat) -> dgamma/dbeta and adds gamma-weighted
+// sums into the level accumulators S1/S2.
+int bn_bwd_finalize(const float* partial, long long nblk, int J, const float* gamma, float* dgamma, float* dbeta,
+                    float* S1, float* S2, hipStream_t s);
+
+// ---- gradient finalisation -----------------------------------------------------------------
+struct GradFinParams {
+  const float* S;  // activation view (channel 0 of the range)
+  const float* G;  // raw gradient accumulation view
+  long long ns;    // sample stride of S and G
+  int C, H, W;     // channels in range, spatial dims of S/G
+  const float* mean;
+  const float* invstd;
+  const float* S1;
+  const float* S2;
+  float invM;
+  const float* nscale;  // [N][C] or null
+  float* dst;           // [N][C][Hd][Wd] contiguous
+  float* bias_partial;  // [rows][C] or null ; rows = N * blocks per plane
+  // pool-backward variant: dst is the pre-pool map (Hd x Wd), S/G are the pooled maps (H x W)
+  const unsigned char* pool_idx;  // [N][C][H][W] or null
+  int Hd, Wd;
+};
+// returns number of bias_partial rows through *rows
+int grad_finalize(const GradFinParams& p, int N, long long* rows, hipStream_t s);
+long long grad_finalize_rows(int N, int Hd, int Wd);
+
+// dst[e] = sum_r src[r*len + e]   (fixed order)
+int reduce_rows(const float* src, long long rows, long long len, float* dst, hipStream_t s);
+
+// ---- head ----------------------------------------------------------------------------------
+struct HeadParams {
+  const float* S;  // [N][C][HW] view of the final stack
+  long long ns;
+  int C, HW, ncls;
+  const float* w;  // [ncls][C]
+  const float* b;  // [ncls]
+  float T;
+};
+int head_forward(const HeadParams& p, int N, float* out, int use_softmax, float* feat_out, hipStream_t s);
+// classifier alone on given features [N][C][HW] contiguous
+int classifier_forward(const HeadParams& p, int N, float* out, int use_softmax, hipStream_t s);
+
+struct LossScratch {   // device scratch owned by the ctx
+  int* counts;         // [ncls + 1] (last = bad labels)
+  float* partial;      // [nblk][4]
+  float* result;       // [0]=num [1]=den [2]=correct ; weights at [4..4+ncls)
+};
+int loss_forward(const float* probs, const long long* y, int N, int ncls, int HW, int weighted, const LossScratch& sc,
+                 float* out, long long* argmax_out, long long* confusion_out, hipStream_t s);
+long long loss_blocks(long long npix);
+
+struct HeadBwdParams {
+  HeadParams h;
+  const long long* y;
+  const float* lossres;  // LossScratch.result
+  float loss_scale;
+  float* G;              // gradient view [N][C][HW] (written: gx / invstd)
+  long long g_ns;
+  const float* invstd;   // [C]
+  float* glin;           // scratch [N][ncls][HW]
+  float* bias_partial;   // [blocks][ncls]
+};
+int head_backward_data(const HeadBwdParams& p, int N, long long* bias_rows, hipStream_t s);
+// dW partial [N][ncls*C]
+int head_backward_weight(const HeadParams& h, int N, const float* glin, float* partial, hipStream_t s);
+
+// ---- misc ----------------------------------------------------------------------------------
+int adamw(float* p, const float* g, float* m, float* v, long long count, float lr, float b1, float b2, float eps,
+          float wd, int step, float grad_scale, hipStream_t s);
+int dropout_scales(float* dst, long long count, float keep, unsigned long long seed, hipStream_t s);
+int add_one_i64(long long* p, long long count, hipStream_t s);
+
+}  // namespace rln

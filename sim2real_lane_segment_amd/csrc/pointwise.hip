@@ -1,0 +1,683 @@
+// HBM-bound kernels (see pointwise.h).  Everything here is wave64 code: per-lane streaming loads
+// that are coalesced along the pixel axis of NCHW planes, wave64 shuffles for reductions, block
+// partials + fixed-order second stage instead of float atomics (bitwise reproducible results).
+#include "pointwise.h"
+
+namespace rln {
+
+#define RLN_LAUNCH_CHECK() return (int)hipGetLastError()
+
+// =============================================================================================
+// BatchNorm bookkeeping
+// =============================================================================================
+
+// one wave per channel: sums the per-block partials in double
+__global__ __launch_bounds__(256) void bn_finalize_k(const float* __restrict__ partial, long long nblk, int J,
+                                                     double count, float eps, float* mean, float* var,
+                                                     float* invstd, float* stdv) {
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= J) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (long long b = lane; b < nblk; b += 64) {
+    s1 += (double)partial[(b * J + j) * 2 + 0];
+    s2 += (double)partial[(b * J + j) * 2 + 1];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
+  }
+  if (lane == 0) {
+    const double m = s1 / count;
+    double v = s2 / count - m * m;
+    if (v < 0.0) v = 0.0;
+    mean[j] = (float)m;
+    var[j] = (float)v;
+    const float sd = sqrtf((float)v + eps);
+    invstd[j] = 1.0f / sd;
+    stdv[j] = sd;
+  }
+}
+
+int bn_finalize(const float* partial, long long nblk, int J, double count, float eps, float* mean, float* var,
+                float* invstd, float* stdv, hipStream_t s) {
+  hipLaunchKernelGGL(bn_finalize_k, dim3((J + 3) / 4), dim3(256), 0, s, partial, nblk, J, count, eps, mean, var,
+                     invstd, stdv);
+  RLN_LAUNCH_CHECK();
+}
+
+__global__ __launch_bounds__(256) void bn_prep_k(int training, int C, const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, const float* __restrict__ mean,
+                                                 const float* __restrict__ var, const float* __restrict__ invstd,
+                                                 float* running_mean, float* running_var, float momentum,
+                                                 float unbias, float eps, float* a, float* b) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  if (training) {
+    const float m = mean[c], is = invstd[c];
+    const float av = gamma[c] * is;
+    a[c] = av;
+    b[c] = beta[c] - m * av;
+    if (running_mean != nullptr) {
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (var[c] * unbias);
+    }
+  } else {
+    const float is = 1.0f / sqrtf(running_var[c] + eps);
+    const float av = gamma[c] * is;
+    a[c] = av;
+    b[c] = beta[c] - running_mean[c] * av;
+  }
+}
+
+int bn_prep(int training, int C, const float* gamma, const float* beta, const float* mean, const float* var,
+            const float* invstd, float* running_mean, float* running_var, float momentum, double count, float eps,
+            float* a, float* b, hipStream_t s) {
+  const float unbias = count > 1.0 ? (float)(count / (count - 1.0)) : 1.0f;
+  hipLaunchKernelGGL(bn_prep_k, dim3((C + 255) / 256), dim3(256), 0, s, training, C, gamma, beta, mean, var, invstd,
+                     running_mean, running_var, momentum, unbias, eps, a, b);
+  RLN_LAUNCH_CHECK();
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_k(const float* __restrict__ partial, long long nblk, int J,
+                                                         const float* __restrict__ gamma, float* dgamma, float* dbeta,
+                                                         float* S1, float* S2) {
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= J) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (long long b = lane; b < nblk; b += 64) {
+    s1 += (double)partial[(b * J + j) * 2 + 0];
+    s2 += (double)partial[(b * J + j) * 2 + 1];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
+  }
+  if (lane == 0) {
+    dbeta[j] = (float)s1;
+    dgamma[j] = (float)s2;
+    const float g = gamma[j];
+    S1[j] += g * (float)s1;
+    S2[j] += g * (float)s2;
+  }
+}
+
+int bn_bwd_finalize(const float* partial, long long nblk, int J, const float* gamma, float* dgamma, float* dbeta,
+                    float* S1, float* S2, hipStream_t s) {
+  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((J + 3) / 4), dim3(256), 0, s, partial, nblk, J, gamma, dgamma, dbeta, S1,
+                     S2);
+  RLN_LAUNCH_CHECK();
+}
+
+// =============================================================================================
+// gradient finalisation:  d/dx = invstd * (G - S1/M - xhat * S2/M)  [* dropout scale]
+// =============================================================================================
+
+__global__ __launch_bounds__(256) void grad_finalize_k(const GradFinParams p) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int tid = threadIdx.x;
+  const float mean = p.mean[c], is = p.invstd[c];
+  const float k1 = p.S1[c] * p.invM, k2 = p.S2[c] * p.invM;
+  float sc = 1.f;
+  if (p.nscale != nullptr) sc = p.nscale[(long long)n * p.C + c];
+  const long long plane = (long long)p.H * p.W;
+  const float* Sp = p.S + (long long)n * p.ns + (long long)c * plane;
+  const float* Gp = p.G + (long long)n * p.ns + (long long)c * plane;
+  const long long dplane = (long long)p.Hd * p.Wd;
+  float* dp = p.dst + ((long long)n * p.C + c) * dplane;
+  float bsum = 0.f;
+  const long long e0 = (long long)blockIdx.x * 1024;
+  if (p.pool_idx == nullptr) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long long e = e0 + i * 256 + tid;
+      if (e < dplane) {
+        const float xh = (Sp[e] - mean) * is;
+        const float v = sc * is * (Gp[e] - k1 - xh * k2);
+        dp[e] = v;
+        bsum += v;
+      }
+    }
+  } else {
+    const unsigned char* ip = p.pool_idx + ((long long)n * p.C + c) * plane;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long long e = e0 + i * 256 + tid;
+      if (e < dplane) {
+        const int yd = (int)(e / p.Wd), xd = (int)(e - (long long)yd * p.Wd);
+        const int py = yd >> 1, px = xd >> 1;
+        float v = 0.f;
+        if (py < p.H && px < p.W) {
+          const long long q = (long long)py * p.W + px;
+          if ((int)ip[q] == (((yd & 1) << 1) | (xd & 1))) {
+            const float xh = (Sp[q] - mean) * is;
+            v = sc * is * (Gp[q] - k1 - xh * k2);
+          }
+        }
+        dp[e] = v;
+        bsum += v;
+      }
+    }
+  }
+  if (p.bias_partial != nullptr) {
+    __shared__ float red[4];
+    bsum = wave_sum64(bsum);
+    if ((tid & 63) == 0) red[tid >> 6] = bsum;
+    __syncthreads();
+    if (tid == 0) {
+      const long long row = (long long)n * gridDim.x + blockIdx.x;
+      p.bias_partial[row * p.C + c] = red[0] + red[1] + red[2] + red[3];
+    }
+  }
+}
+
+long long grad_finalize_rows(int N, int Hd, int Wd) {
+  const long long nbx = ((long long)Hd * Wd + 1023) / 1024;
+  return nbx * N;
+}
+
+int grad_finalize(const GradFinParams& p, int N, long long* rows, hipStream_t s) {
+  const long long nbx = ((long long)p.Hd * p.Wd + 1023) / 1024;
+  if (rows) *rows = nbx * N;
+  hipLaunchKernelGGL(grad_finalize_k, dim3((unsigned)nbx, (unsigned)p.C, (unsigned)N), dim3(256), 0, s, p);
+  RLN_LAUNCH_CHECK();
+}
+
+__global__ __launch_bounds__(256) void reduce_rows_k(const float* __restrict__ src, long long rows, long long len,
+                                                     float* dst) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= len) return;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  long long r = 0;
+  for (; r + 3 < rows; r += 4) {
+    a0 += src[r * len + e];
+    a1 += src[(r + 1) * len + e];
+    a2 += src[(r + 2) * len + e];
+    a3 += src[(r + 3) * len + e];
+  }
+  for (; r < rows; ++r) a0 += src[r * len + e];
+  dst[e] = (a0 + a1) + (a2 + a3);
+}
+
+// few long columns (bias gradients): one wave per column, double accumulation
+__global__ __launch_bounds__(256) void reduce_rows_tall_k(const float* __restrict__ src, long long rows, long long len,
+                                                          float* dst) {
+  const int lane = threadIdx.x & 63;
+  const long long e = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (e >= len) return;
+  double a = 0.0;
+  for (long long r = lane; r < rows; r += 64) a += (double)src[r * len + e];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+  if (lane == 0) dst[e] = (float)a;
+}
+
+int reduce_rows(const float* src, long long rows, long long len, float* dst, hipStream_t s) {
+  if (len <= 4096 && rows >= 64) {
+    hipLaunchKernelGGL(reduce_rows_tall_k, dim3((unsigned)((len + 3) / 4)), dim3(256), 0, s, src, rows, len, dst);
+  } else {
+    hipLaunchKernelGGL(reduce_rows_k, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s, src, rows, len, dst);
+  }
+  RLN_LAUNCH_CHECK();
+}
+
+// =============================================================================================
+// head: F.normalize (tiramisu.py:105) + 1x1 classifier, /T, softmax (tiramisu.py:120-125)
+// =============================================================================================
+
+constexpr int HEAD_MAXC = 1024;  // feature channels supported by the LDS weight image
+
+template <int NC>
+__device__ __forceinline__ void load_head_weights(float* wt, float* bt, const HeadParams& p) {
+  for (int e = threadIdx.x; e < p.C * NC; e += 256) {
+    const int c = e / NC, k = e - c * NC;
+    wt[e] = (k < p.ncls) ? p.w[(long long)k * p.C + c] : 0.f;
+  }
+  if (threadIdx.x < NC) bt[threadIdx.x] = (threadIdx.x < p.ncls) ? p.b[threadIdx.x] : 0.f;
+}
+
+template <int NC>
+__device__ __forceinline__ void softmax_nc(float* l, int ncls) {
+  float m = l[0];
+#pragma unroll
+  for (int k = 1; k < NC; ++k)
+    if (k < ncls) m = fmaxf(m, l[k]);
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    l[k] = (k < ncls) ? expf(l[k] - m) : 0.f;
+    sum += l[k];
+  }
+  const float inv = 1.f / sum;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) l[k] *= inv;
+}
+
+// NORMALIZE: input is the raw stack (fused feature extractor tail); else input already normalised
+template <int NC, bool NORMALIZE>
+__global__ __launch_bounds__(256) void head_fwd_k(const HeadParams p, float* out, int use_softmax, float* feat_out) {
+  extern __shared__ __align__(16) float hsm[];
+  float* wt = hsm;
+  float* bt = hsm + (long long)p.C * NC;
+  load_head_weights<NC>(wt, bt, p);
+  __syncthreads();
+  const int n = blockIdx.y;
+  const long long px = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (px >= p.HW) return;
+  const float* xp = p.S + (long long)n * p.ns + px;
+  float d[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) d[k] = 0.f;
+  float ss = 0.f;
+#pragma unroll 8
+  for (int c = 0; c < p.C; ++c) {
+    const float x = xp[(long long)c * p.HW];
+    ss = fmaf(x, x, ss);
+#pragma unroll
+    for (int k = 0; k < NC; ++k) d[k] = fmaf(wt[c * NC + k], x, d[k]);
+  }
+  float inv = 1.f;
+  if (NORMALIZE) inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+  float l[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) l[k] = (d[k] * inv + bt[k]) / p.T;
+  if (use_softmax) softmax_nc<NC>(l, p.ncls);
+  if (out != nullptr) {
+#pragma unroll
+    for (int k = 0; k < NC; ++k)
+      if (k < p.ncls) out[((long long)n * p.ncls + k) * p.HW + px] = l[k];
+  }
+  if (feat_out != nullptr) {
+    float* fp = feat_out + (long long)n * p.C * p.HW + px;
+#pragma unroll 8
+    for (int c = 0; c < p.C; ++c) fp[(long long)c * p.HW] = xp[(long long)c * p.HW] * inv;
+  }
+}
+
+template <bool NORMALIZE>
+static int head_launch(const HeadParams& p, int N, float* out, int use_softmax, float* feat_out, hipStream_t s) {
+  if (p.C > HEAD_MAXC || p.ncls > 16 || p.ncls < 1) return -4;
+  dim3 grid((unsigned)((p.HW + 255) / 256), (unsigned)N);
+  if (p.ncls <= 4) {
+    hipLaunchKernelGGL((head_fwd_k<4, NORMALIZE>), grid, dim3(256), (p.C * 4 + 4) * 4, s, p, out, use_softmax,
+                       feat_out);
+  } else if (p.ncls <= 8) {
+    hipLaunchKernelGGL((head_fwd_k<8, NORMALIZE>), grid, dim3(256), (p.C * 8 + 8) * 4, s, p, out, use_softmax,
+                       feat_out);
+  } else {
+    hipLaunchKernelGGL((head_fwd_k<16, NORMALIZE>), grid, dim3(256), (p.C * 16 + 16) * 4, s, p, out, use_softmax,
+                       feat_out);
+  }
+  RLN_LAUNCH_CHECK();
+}
+
+int head_forward(const HeadParams& p, int N, float* out, int use_softmax, float* feat_out, hipStream_t s) {
+  return head_launch<true>(p, N, out, use_softmax, feat_out, s);
+}
+int classifier_forward(const HeadParams& p, int N, float* out, int use_softmax, hipStream_t s) {
+  return head_launch<false>(p, N, out, use_softmax, nullptr, s);
+}
+
+// =============================================================================================
+// loss: class histogram -> weights, CE on probabilities (double softmax), argmax, accuracy
+// (SimpleTrain.py:15-20, TrainingBase.py:12-23,84-87)
+// =============================================================================================
+
+__global__ __launch_bounds__(256) void loss_hist_k(const long long* __restrict__ y, long long npix, int ncls,
+                                                   int* counts) {
+  __shared__ int h[17];
+  if (threadIdx.x < 17) h[threadIdx.x] = 0;
+  __syncthreads();
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long long)gridDim.x * 256) {
+    const long long v = y[i];
+    const int k = (v >= 0 && v < ncls) ? (int)v : 16;
+    atomicAdd(&h[k], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < ncls && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], h[threadIdx.x]);
+  if (threadIdx.x == 16 && h[16]) atomicAdd(&counts[ncls], h[16]);
+}
+
+__global__ void loss_weights_k(const int* counts, int ncls, int weighted, float* result) {
+  const int k = threadIdx.x;
+  if (k < ncls) result[4 + k] = weighted ? (1.0f / (float)counts[k]) : 1.0f;
+}
+
+constexpr int LOSS_PIX_PER_BLOCK = 1024;
+long long loss_blocks(long long npix) { return (npix + LOSS_PIX_PER_BLOCK - 1) / LOSS_PIX_PER_BLOCK; }
+
+template <int NC>
+__global__ __launch_bounds__(256) void loss_main_k(const float* __restrict__ probs, const long long* __restrict__ y,
+                                                   int ncls, long long HW, long long npix,
+                                                   const float* __restrict__ result, float* partial,
+                                                   long long* argmax_out, int* conf) {
+  float num = 0.f, den = 0.f, cor = 0.f;
+#pragma unroll
+  for (int i = 0; i < LOSS_PIX_PER_BLOCK / 256; ++i) {
+    const long long g = (long long)blockIdx.x * LOSS_PIX_PER_BLOCK + i * 256 + threadIdx.x;
+    if (g < npix) {
+      const long long n = g / HW, px = g - n * HW;
+      float pr[NC];
+#pragma unroll
+      for (int k = 0; k < NC; ++k) pr[k] = (k < ncls) ? probs[(n * ncls + k) * HW + px] : 0.f;
+      float m = pr[0];
+      int am = 0;
+#pragma unroll
+      for (int k = 1; k < NC; ++k)
+        if (k < ncls && pr[k] > m) {
+          m = pr[k];
+          am = k;
+        }
+      float se = 0.f;
+#pragma unroll
+      for (int k = 0; k < NC; ++k)
+        if (k < ncls) se += expf(pr[k] - m);
+      const float lse = m + logf(se);
+      const long long lab = y[g];
+      if (lab >= 0 && lab < ncls) {
+        float py = 0.f;
+#pragma unroll
+        for (int k = 0; k < NC; ++k)
+          if (k == (int)lab) py = pr[k];
+        const float w = result[4 + (int)lab];
+        num += w * (lse - py);
+        den += w;
+        cor += (am == (int)lab) ? 1.f : 0.f;
+        if (conf != nullptr) atomicAdd(&conf[(int)lab * ncls + am], 1);
+      }
+      if (argmax_out != nullptr) argmax_out[g] = am;
+    }
+  }
+  __shared__ float red[4][3];
+  num = wave_sum64(num);
+  den = wave_sum64(den);
+  cor = wave_sum64(cor);
+  if ((threadIdx.x & 63) == 0) {
+    red[threadIdx.x >> 6][0] = num;
+    red[threadIdx.x >> 6][1] = den;
+    red[threadIdx.x >> 6][2] = cor;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3)
+    partial[(long long)blockIdx.x * 4 + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void loss_finalize_k(const float* __restrict__ partial, long long nblk, long long npix,
+                                                       int ncls, const int* counts, float* result, float* out,
+                                                       const int* conf, long long* confusion_out) {
+  double a[3] = {0.0, 0.0, 0.0};
+  for (long long b = threadIdx.x; b < nblk; b += 256) {
+    a[0] += (double)partial[b * 4 + 0];
+    a[1] += (double)partial[b * 4 + 1];
+    a[2] += (double)partial[b * 4 + 2];
+  }
+  __shared__ double red[4][3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a[k] += __shfl_xor(a[k], o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = a[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double num = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+    const double den = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+    const double cor = red[0][2] + red[1][2] + red[2][2] + red[3][2];
+    result[0] = (float)num;
+    result[1] = (float)den;
+    result[2] = (float)cor;
+    if (out != nullptr) {
+      out[0] = (float)(num / den);
+      out[1] = (float)(cor / (double)npix);
+      out[2] = (float)counts[ncls];
+      for (int k = 0; k < ncls; ++k) out[3 + k] = (float)counts[k];
+    }
+  }
+  if (confusion_out != nullptr && conf != nullptr && threadIdx.x < ncls * ncls)
+    confusion_out[threadIdx.x] = (long long)conf[threadIdx.x];
+}
+
+int loss_forward(const float* probs, const long long* y, int N, int ncls, int HW, int weighted, const LossScratch& sc,
+                 float* out, long long* argmax_out, long long* confusion_out, hipStream_t s) {
+  if (ncls > 16 || ncls < 1) return -4;
+  const long long npix = (long long)N * HW;
+  int* conf = confusion_out ? (sc.counts + 32) : nullptr;
+  hipError_t e = hipMemsetAsync(sc.counts, 0, sizeof(int) * (32 + 256), s);
+  if (e != hipSuccess) return (int)e;
+  long long hb = (npix + 255) / 256;
+  if (hb > 1024) hb = 1024;
+  hipLaunchKernelGGL(loss_hist_k, dim3((unsigned)hb), dim3(256), 0, s, y, npix, ncls, sc.counts);
+  hipLaunchKernelGGL(loss_weights_k, dim3(1), dim3(64), 0, s, sc.counts, ncls, weighted, sc.result);
+  const long long nblk = loss_blocks(npix);
+  if (ncls <= 4) {
+    hipLaunchKernelGGL(loss_main_k<4>, dim3((unsigned)nblk), dim3(256), 0, s, probs, y, ncls, (long long)HW, npix,
+                       sc.result, sc.partial, argmax_out, conf);
+  } else if (ncls <= 8) {
+    hipLaunchKernelGGL(loss_main_k<8>, dim3((unsigned)nblk), dim3(256), 0, s, probs, y, ncls, (long long)HW, npix,
+                       sc.result, sc.partial, argmax_out, conf);
+  } else {
+    hipLaunchKernelGGL(loss_main_k<16>, dim3((unsigned)nblk), dim3(256), 0, s, probs, y, ncls, (long long)HW, npix,
+                       sc.result, sc.partial, argmax_out, conf);
+  }
+  hipLaunchKernelGGL(loss_finalize_k, dim3(1), dim3(256), 0, s, sc.partial, nblk, npix, ncls, sc.counts, sc.result, out,
+                     conf, confusion_out);
+  RLN_LAUNCH_CHECK();
+}
+
+// =============================================================================================
+// head backward.  Per pixel: recompute forward, d(loss)/d(probabilities) of the weighted CE on
+// probabilities, back through softmax, /T, 1x1 conv and F.normalize.
+// =============================================================================================
+
+template <int NC>
+__global__ __launch_bounds__(256) void head_bwd_data_k(const HeadBwdParams q) {
+  const HeadParams& p = q.h;
+  extern __shared__ __align__(16) float hsm[];
+  float* wt = hsm;
+  float* bt = hsm + (long long)p.C * NC;
+  float* red = bt + NC;  // [4][NC]
+  load_head_weights<NC>(wt, bt, p);
+  __syncthreads();
+  const int n = blockIdx.y;
+  const long long px = (long long)blockIdx.x * 256 + threadIdx.x;
+  const bool active = px < p.HW;
+  float gl[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) gl[k] = 0.f;
+  if (active) {
+    const float* xp = p.S + (long long)n * p.ns + px;
+    float d[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) d[k] = 0.f;
+    float ss = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < p.C; ++c) {
+      const float x = xp[(long long)c * p.HW];
+      ss = fmaf(x, x, ss);
+#pragma unroll
+      for (int k = 0; k < NC; ++k) d[k] = fmaf(wt[c * NC + k], x, d[k]);
+    }
+    const float nrm = sqrtf(ss);
+    const bool proj = nrm > 1e-12f;
+    const float inv = 1.f / fmaxf(nrm, 1e-12f);
+    float pr[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) pr[k] = (d[k] * inv + bt[k]) / p.T;
+    softmax_nc<NC>(pr, p.ncls);
+    // second softmax (cross_entropy applies log_softmax to the probabilities)
+    float qq[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) qq[k] = pr[k];
+    softmax_nc<NC>(qq, p.ncls);
+    const long long lab = q.y[(long long)n * p.HW + px];
+    float wy = 0.f;
+    if (lab >= 0 && lab < p.ncls) wy = q.lossres[4 + (int)lab];
+    const float coef = q.loss_scale * wy / q.lossres[1];
+    float gp[NC];
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      gp[k] = (k < p.ncls) ? coef * (qq[k] - ((k == (int)lab) ? 1.f : 0.f)) : 0.f;
+      dot = fmaf(pr[k], gp[k], dot);
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      gl[k] = (k < p.ncls) ? pr[k] * (gp[k] - dot) / p.T : 0.f;
+      t = fmaf(gl[k], d[k], t);
+    }
+    t = proj ? t * inv : 0.f;  // = sum_c gxn[c] * xn[c]
+    float* gout = q.G + (long long)n * q.g_ns + px;
+#pragma unroll 8
+    for (int c = 0; c < p.C; ++c) {
+      const float x = xp[(long long)c * p.HW];
+      float gxn = 0.f;
+#pragma unroll
+      for (int k = 0; k < NC; ++k) gxn = fmaf(wt[c * NC + k], gl[k], gxn);
+      const float gx = (gxn - x * inv * t) * inv;
+      gout[(long long)c * p.HW] = gx / q.invstd[c];
+    }
+#pragma unroll
+    for (int k = 0; k < NC; ++k)
+      if (k < p.ncls) q.glin[((long long)n * p.ncls + k) * p.HW + px] = gl[k] * inv;
+  }
+  // bias gradient partial: sum of gl[k] over the block
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const float v = wave_sum64(gl[k]);
+    if ((threadIdx.x & 63) == 0) red[(threadIdx.x >> 6) * NC + k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < p.ncls) {
+    const int k = threadIdx.x;
+    const long long row = (long long)n * gridDim.x + blockIdx.x;
+    q.bias_partial[row * p.ncls + k] = red[k] + red[NC + k] + red[2 * NC + k] + red[3 * NC + k];
+  }
+}
+
+int head_backward_data(const HeadBwdParams& q, int N, long long* bias_rows, hipStream_t s) {
+  const HeadParams& p = q.h;
+  if (p.C > HEAD_MAXC || p.ncls > 16 || p.ncls < 1) return -4;
+  dim3 grid((unsigned)((p.HW + 255) / 256), (unsigned)N);
+  if (bias_rows) *bias_rows = (long long)grid.x * N;
+  if (p.ncls <= 4) {
+    hipLaunchKernelGGL(head_bwd_data_k<4>, grid, dim3(256), (p.C * 4 + 4 + 16) * 4, s, q);
+  } else if (p.ncls <= 8) {
+    hipLaunchKernelGGL(head_bwd_data_k<8>, grid, dim3(256), (p.C * 8 + 8 + 32) * 4, s, q);
+  } else {
+    hipLaunchKernelGGL(head_bwd_data_k<16>, grid, dim3(256), (p.C * 16 + 16 + 64) * 4, s, q);
+  }
+  RLN_LAUNCH_CHECK();
+}
+
+// dW[k][c] partial per sample: block = (channel c, sample n)
+template <int NC>
+__global__ __launch_bounds__(256) void head_bwd_weight_k(const HeadParams p, const float* __restrict__ glin,
+                                                         float* partial) {
+  const int c = blockIdx.x, n = blockIdx.y;
+  const float* xp = p.S + (long long)n * p.ns + (long long)c * p.HW;
+  const float* gp = glin + (long long)n * p.ncls * p.HW;
+  float acc[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) acc[k] = 0.f;
+  for (long long px = threadIdx.x; px < p.HW; px += 256) {
+    const float x = xp[px];
+#pragma unroll
+    for (int k = 0; k < NC; ++k)
+      if (k < p.ncls) acc[k] = fmaf(gp[(long long)k * p.HW + px], x, acc[k]);
+  }
+  __shared__ float red[4][NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const float v = wave_sum64(acc[k]);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < p.ncls) {
+    const int k = threadIdx.x;
+    partial[(long long)n * p.ncls * p.C + (long long)k * p.C + c] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+  }
+}
+
+int head_backward_weight(const HeadParams& p, int N, const float* glin, float* partial, hipStream_t s) {
+  dim3 grid((unsigned)p.C, (unsigned)N);
+  if (p.ncls <= 4) {
+    hipLaunchKernelGGL(head_bwd_weight_k<4>, grid, dim3(256), 0, s, p, glin, partial);
+  } else if (p.ncls <= 8) {
+    hipLaunchKernelGGL(head_bwd_weight_k<8>, grid, dim3(256), 0, s, p, glin, partial);
+  } else {
+    hipLaunchKernelGGL(head_bwd_weight_k<16>, grid, dim3(256), 0, s, p, glin, partial);
+  }
+  RLN_LAUNCH_CHECK();
+}
+
+// =============================================================================================
+// AdamW (torch.optim.AdamW single-tensor formulas, SimpleTrain.py:28), dropout masks, counters
+// =============================================================================================
+
+__global__ __launch_bounds__(256) void adamw_k(float* __restrict__ p, const float* __restrict__ g,
+                                               float* __restrict__ m, float* __restrict__ v, long long count,
+                                               float decay_mul, float b1, float b2, float eps, float step_size,
+                                               float bc2_sqrt, float grad_scale) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  const float gi = g[i] * grad_scale;
+  float pi = p[i] * decay_mul;
+  float mi = m[i];
+  mi = mi + (gi - mi) * (1.f - b1);          // exp_avg.lerp_(grad, 1 - beta1)
+  const float vi = v[i] * b2 + (1.f - b2) * gi * gi;  // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  pi = pi - step_size * (mi / denom);
+  p[i] = pi;
+  m[i] = mi;
+  v[i] = vi;
+}
+
+int adamw(float* p, const float* g, float* m, float* v, long long count, float lr, float b1, float b2, float eps,
+          float wd, int step, float grad_scale, hipStream_t s) {
+  const double bc1 = 1.0 - pow((double)b1, (double)step);
+  const double bc2 = 1.0 - pow((double)b2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  const float decay_mul = (float)(1.0 - (double)lr * (double)wd);
+  hipLaunchKernelGGL(adamw_k, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, p, g, m, v, count, decay_mul, b1,
+                     b2, eps, step_size, bc2_sqrt, grad_scale);
+  RLN_LAUNCH_CHECK();
+}
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+// counter-based Bernoulli(keep) per (dropout call, sample, channel): 0 or 1/keep
+__global__ __launch_bounds__(256) void dropout_k(float* dst, long long count, float keep, unsigned long long seed) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  const unsigned long long r = mix64(mix64(seed) ^ (unsigned long long)i);
+  const float u = (float)(r >> 40) * (1.0f / 16777216.0f);
+  dst[i] = (u < keep) ? (1.0f / keep) : 0.f;
+}
+
+int dropout_scales(float* dst, long long count, float keep, unsigned long long seed, hipStream_t s) {
+  hipLaunchKernelGGL(dropout_k, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, dst, count, keep, seed);
+  RLN_LAUNCH_CHECK();
+}
+
+__global__ void add_one_k(long long* p, long long count) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < count) p[i] += 1;
+}
+
+int add_one_i64(long long* p, long long count, hipStream_t s) {
+  hipLaunchKernelGGL(add_one_k, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, p, count);
+  RLN_LAUNCH_CHECK();
+}
+
+}  // namespace rln

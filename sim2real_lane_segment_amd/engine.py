@@ -1,0 +1,247 @@
+"""Host-side owner of one ``rln_ctx``: flat device arenas, workspace, and the forward / loss /
+backward / AdamW calls of the C ABI (include/rln.h).  PyTorch is used for device memory and
+streams only; every arithmetic op of the path runs in librln.so.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+
+@dataclass(frozen=True)
+class NetSpec:
+    """Constructor knobs of FCDenseNetFeatureExtractor/Classifier (models/FCDenseNet/tiramisu.py:21-24,112-118)."""
+    in_channels: int = 3
+    down_blocks: Tuple[int, ...] = (5, 5, 5, 5, 5)
+    up_blocks: Tuple[int, ...] = (5, 5, 5, 5, 5)
+    bottleneck_layers: int = 5
+    growth_rate: int = 16
+    out_chans_first_conv: int = 48
+    n_classes: int = 2
+    temperature: float = 0.05
+
+
+@dataclass
+class TensorMeta:
+    name: str
+    kind: int
+    offset: int
+    shape: Tuple[int, ...]
+
+    @property
+    def numel(self):
+        n = 1
+        for s in self.shape:
+            n *= s
+        return n
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Engine:
+    """One network instance on one device.
+
+    ``params``/``grads`` are flat fp32 arenas in forward execution order; ``views[name]`` are
+    tensors aliasing them under the reference's state_dict names.
+    """
+
+    def __init__(self, spec: NetSpec, device="cpu"):
+        self.spec = spec
+        self.L = _lib.lib()
+        cfg = _lib.make_config(spec.in_channels, spec.down_blocks, spec.up_blocks, spec.bottleneck_layers,
+                               spec.growth_rate, spec.out_chans_first_conv, spec.n_classes, spec.temperature)
+        handle = ctypes.c_void_p()
+        _lib.check(self.L.rln_create(ctypes.byref(cfg), ctypes.byref(handle)), "rln_create")
+        self.ctx = handle
+        self.metas: List[TensorMeta] = []
+        name = ctypes.create_string_buffer(256)
+        kind, off, ndim = ctypes.c_int(), ctypes.c_int64(), ctypes.c_int()
+        shape = (ctypes.c_int64 * 4)()
+        for i in range(self.L.rln_num_tensors(self.ctx)):
+            _lib.check(self.L.rln_tensor_info(self.ctx, i, name, 256, ctypes.byref(kind), ctypes.byref(off),
+                                              ctypes.byref(ndim), shape), "rln_tensor_info")
+            self.metas.append(TensorMeta(name.value.decode(), kind.value, off.value,
+                                         tuple(int(shape[k]) for k in range(ndim.value))))
+        self.n_param = int(self.L.rln_param_count(self.ctx))
+        self.n_bnstat = int(self.L.rln_bnstat_count(self.ctx))
+        self.n_nbt = int(self.L.rln_nbt_count(self.ctx))
+        self.feature_channels = int(self.L.rln_feature_channels(self.ctx))
+        nd = self.L.rln_num_dropouts(self.ctx)
+        per = (ctypes.c_int * max(nd, 1))()
+        self.drop_total = int(self.L.rln_dropout_channels(self.ctx, per))
+        self.drop_channels = [int(per[i]) for i in range(nd)]
+        self.n_seg = int(self.L.rln_backward_segments(self.ctx))
+        self.seg_ranges = []
+        b, e = ctypes.c_int64(), ctypes.c_int64()
+        for s in range(self.n_seg):
+            _lib.check(self.L.rln_backward_segment_range(self.ctx, s, ctypes.byref(b), ctypes.byref(e)))
+            self.seg_ranges.append((b.value, e.value))
+        self.device = torch.device("cpu")
+        self.params = self.grads = self.bnrun = self.nbt = None
+        self.views: Dict[str, torch.Tensor] = {}
+        self.grad_views: Dict[str, torch.Tensor] = {}
+        self._ws = None
+        self._ws_key = None
+        self._keep = []
+        self.step_seed = 0
+        self.allocate(device)
+
+    def __del__(self):
+        try:
+            if getattr(self, "ctx", None):
+                self.L.rln_destroy(self.ctx)
+                self.ctx = None
+        except Exception:
+            pass
+
+    # ---- arenas ---------------------------------------------------------------------------
+    def allocate(self, device, old: Optional["Engine"] = None):
+        """(Re)allocates the arenas on ``device`` keeping current values."""
+        device = torch.device(device)
+        prev = (self.params, self.bnrun, self.nbt)
+        self.params = torch.zeros(self.n_param, dtype=torch.float32, device=device)
+        self.grads = torch.zeros(self.n_param, dtype=torch.float32, device=device)
+        self.bnrun = torch.zeros(self.n_bnstat, dtype=torch.float32, device=device)
+        self.nbt = torch.zeros(self.n_nbt, dtype=torch.int64, device=device)
+        if prev[0] is not None:
+            self.params.copy_(prev[0])
+            self.bnrun.copy_(prev[1])
+            self.nbt.copy_(prev[2])
+        self.device = device
+        self.views, self.grad_views = {}, {}
+        for m in self.metas:
+            if m.kind == _lib.T_PARAM:
+                self.views[m.name] = self.params[m.offset:m.offset + m.numel].view(m.shape)
+                self.grad_views[m.name] = self.grads[m.offset:m.offset + m.numel].view(m.shape)
+            elif m.kind in (_lib.T_RUNNING_MEAN, _lib.T_RUNNING_VAR):
+                self.views[m.name] = self.bnrun[m.offset:m.offset + m.numel].view(m.shape)
+            else:
+                self.views[m.name] = self.nbt[m.offset]
+        self._ws = None
+        self._ws_key = None
+        if device.type == "cuda":
+            _lib.check(self.L.rln_bind_params(self.ctx, _ptr(self.params), _ptr(self.grads), _ptr(self.bnrun),
+                                              _ptr(self.nbt)), "rln_bind_params")
+
+    def load_state(self, state: Dict[str, torch.Tensor]):
+        for m in self.metas:
+            self.views[m.name].copy_(state[m.name])
+
+    def state(self) -> Dict[str, torch.Tensor]:
+        return {m.name: self.views[m.name].detach().clone() for m in self.metas}
+
+    # ---- workspace ------------------------------------------------------------------------
+    def _require_gpu(self):
+        if self.device.type != "cuda":
+            raise RuntimeError("the lane-segmentation path runs on the GPU only (HIP kernels); "
+                               "move the module with .cuda() -- there is no CPU fallback")
+
+    def ensure_workspace(self, n, h, w, with_backward):
+        self._require_gpu()
+        key = (n, h, w)
+        if self._ws_key is not None and self._ws_key[:3] == key and (self._ws_key[3] or not with_backward):
+            return
+        need = int(self.L.rln_workspace_bytes(self.ctx, n, h, w, int(with_backward)))
+        self._ws = None  # release before allocating the next one
+        self._ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+        base = self._ws.data_ptr()
+        aligned = (base + 255) // 256 * 256
+        _lib.check(self.L.rln_set_workspace(self.ctx, ctypes.c_void_p(aligned), need, n, h, w, int(with_backward)),
+                   "rln_set_workspace")
+        self._ws_key = (n, h, w, bool(with_backward))
+
+    # ---- compute --------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, training: bool, with_backward: bool = False,
+                drop_scales: Optional[torch.Tensor] = None, seed: Optional[int] = None, want_probs=True,
+                want_feat=False, use_softmax=True):
+        self._require_gpu()
+        if x.dim() != 4 or x.shape[1] != self.spec.in_channels:
+            raise RuntimeError(f"expected input [N,{self.spec.in_channels},H,W], got {tuple(x.shape)}")
+        x = x.to(device=self.device, dtype=torch.float32).contiguous()
+        n, _, h, w = x.shape
+        self.ensure_workspace(n, h, w, with_backward)
+        probs = torch.empty((n, self.spec.n_classes, h, w), dtype=torch.float32, device=self.device) \
+            if want_probs else None
+        feat = torch.empty((n, self.feature_channels, h, w), dtype=torch.float32, device=self.device) \
+            if want_feat else None
+        if drop_scales is not None:
+            drop_scales = drop_scales.to(device=self.device, dtype=torch.float32).contiguous()
+            if drop_scales.numel() != n * self.drop_total:
+                raise RuntimeError("drop_scales has the wrong size")
+        if seed is None:
+            self.step_seed += 1
+            seed = self.step_seed
+        _lib.check(self.L.rln_forward(self.ctx, _ptr(x), n, h, w, int(training), _ptr(drop_scales), int(seed),
+                                      _ptr(probs), _ptr(feat), int(use_softmax), _stream()), "rln_forward")
+        self._keep = [x, drop_scales]  # the backward pass re-reads the input
+        return probs, feat
+
+    def pack_drop_scales(self, scales: Sequence[torch.Tensor]) -> torch.Tensor:
+        """list of [N, C_call] tensors (oracle layout) -> flat call-major device tensor."""
+        assert len(scales) == len(self.drop_channels)
+        return torch.cat([s.reshape(-1).float() for s in scales]).to(self.device)
+
+    def loss(self, probs: torch.Tensor, y: torch.Tensor, weighted: bool, want_argmax=False, want_confusion=False):
+        self._require_gpu()
+        n, k, h, w = probs.shape
+        y = y.to(device=self.device, dtype=torch.int64).contiguous()
+        out = torch.empty(3 + k, dtype=torch.float32, device=self.device)
+        am = torch.empty((n, h, w), dtype=torch.int64, device=self.device) if want_argmax else None
+        conf = torch.empty((k, k), dtype=torch.int64, device=self.device) if want_confusion else None
+        _lib.check(self.L.rln_loss(self.ctx, _ptr(probs), _ptr(y), n, h, w, int(weighted), _ptr(out), _ptr(am),
+                                   _ptr(conf), _stream()), "rln_loss")
+        self._keep.append(y)
+        return out, am, conf
+
+    def backward(self, loss_scale: float = 1.0, seg_begin: int = 0, seg_end: Optional[int] = None):
+        self._require_gpu()
+        if seg_end is None:
+            seg_end = self.n_seg
+        _lib.check(self.L.rln_backward(self.ctx, float(loss_scale), seg_begin, seg_end, _stream()), "rln_backward")
+
+    def adamw_step(self, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
+                   grad_scale=1.0, lo=0, hi=None):
+        self._require_gpu()
+        hi = self.n_param if hi is None else hi
+        _lib.check(self.L.rln_adamw_step(_ptr(self.params[lo:hi]), _ptr(self.grads[lo:hi]), _ptr(exp_avg[lo:hi]),
+                                         _ptr(exp_avg_sq[lo:hi]), hi - lo, lr, betas[0], betas[1], eps,
+                                         weight_decay, int(step), grad_scale, _stream()), "rln_adamw_step")
+
+
+def _adamw_step_ptr(self, grads_ptr, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
+                    grad_scale=1.0):
+    """AdamW over the whole arena with gradients at an arbitrary flat device address."""
+    self._require_gpu()
+    _lib.check(self.L.rln_adamw_step(_ptr(self.params), ctypes.c_void_p(grads_ptr), _ptr(exp_avg), _ptr(exp_avg_sq),
+                                     self.n_param, lr, betas[0], betas[1], eps, weight_decay, int(step), grad_scale,
+                                     _stream()), "rln_adamw_step")
+
+
+Engine.adamw_step_ptr = _adamw_step_ptr
+
+
+def classifier_op(feat, weight, bias, temperature, use_softmax=True):
+    """FCDenseNetClassifier.forward on arbitrary features (tiramisu.py:120-125)."""
+    L = _lib.lib()
+    if feat.device.type != "cuda":
+        raise RuntimeError("classifier runs on the GPU only (HIP kernels); no CPU fallback")
+    feat = feat.float().contiguous()
+    n, c, h, w = feat.shape
+    k = weight.shape[0]
+    wt = weight.detach().reshape(k, c).float().contiguous()
+    bt = bias.detach().float().contiguous()
+    out = torch.empty((n, k, h, w), dtype=torch.float32, device=feat.device)
+    _lib.check(L.rln_op_classifier(_ptr(feat), n, c, h * w, _ptr(wt), _ptr(bt), k, float(temperature), _ptr(out),
+                                   int(use_softmax), _stream()), "rln_op_classifier")
+    return out

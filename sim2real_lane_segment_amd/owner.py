@@ -1,0 +1,195 @@
+"""Glue between torch.nn parameter containers and the flat-arena HIP engine.
+
+An *owner* is a module holding a ``featureExtractor`` (and optionally a ``classifier``): it creates
+one ``Engine`` and re-points every Parameter / buffer of those sub-modules at views of the
+engine's flat device arenas (``param.data = view`` keeps Parameter identity, so optimisers,
+``state_dict``/``load_state_dict``, ``.parameters()`` and Lightning keep working unchanged).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .engine import Engine, NetSpec
+
+
+def _resolve(root: nn.Module, dotted: str):
+    mod = root
+    parts = dotted.split(".")
+    for p in parts[:-1]:
+        mod = getattr(mod, p) if not p.isdigit() else mod[int(p)]
+    return mod, parts[-1]
+
+
+class EngineOwner:
+    """Mixin. Subclass must be an nn.Module with ``featureExtractor`` (+ optional ``classifier``)."""
+
+    _rln_engine: Optional[Engine] = None
+    _rln_dirty: bool = True
+    _rln_dummy_classifier = None
+
+    def _rln_spec(self) -> NetSpec:
+        fe = self.featureExtractor
+        cl = getattr(self, "classifier", None)
+        n_cls = cl.finalConv.out_channels if cl is not None else 1
+        temp = cl.T if cl is not None else 0.05
+        if cl is not None and tuple(cl.finalConv.kernel_size) != (1, 1):
+            raise RuntimeError("only kernel_size=1 classifiers run on the HIP path")
+        return NetSpec(in_channels=fe.in_channels, down_blocks=tuple(fe.down_blocks), up_blocks=tuple(fe.up_blocks),
+                       bottleneck_layers=fe.bottleneck_layers, growth_rate=fe.growth_rate,
+                       out_chans_first_conv=fe.out_chans_first_conv, n_classes=n_cls, temperature=float(temp))
+
+    def _rln_named_tensors(self) -> Dict[str, torch.Tensor]:
+        out = {}
+        for prefix in ("featureExtractor", "classifier"):
+            mod = getattr(self, prefix, None)
+            if mod is None:
+                continue
+            for k, v in mod.state_dict(keep_vars=True).items():
+                out[f"{prefix}.{k}"] = v
+        return out
+
+    def _rln_current_device(self):
+        return next(self.featureExtractor.parameters()).device
+
+    def _rln_mark_dirty(self):
+        object.__setattr__(self, "_rln_dirty", True)
+
+    def _rln_sync(self) -> Engine:
+        """Makes sure every parameter/buffer aliases the engine arenas on the module's device."""
+        dev = self._rln_current_device()
+        eng = self._rln_engine
+        if eng is not None and not self._rln_dirty and eng.device == dev:
+            return eng
+        current = self._rln_named_tensors()
+        if eng is None:
+            eng = Engine(self._rln_spec(), device=dev)
+            object.__setattr__(self, "_rln_engine", eng)
+        else:
+            eng.allocate(dev)
+        names = []
+        for m in eng.metas:
+            src = current.get(m.name)
+            if src is None:
+                if m.name.startswith("classifier."):  # feature extractor used alone: dummy classifier stays zero
+                    continue
+                raise RuntimeError(f"module has no tensor named {m.name}")
+            view = eng.views[m.name]
+            with torch.no_grad():
+                view.copy_(src.detach().to(view.device))
+            root_name, rest = m.name.split(".", 1)
+            holder, attr = _resolve(getattr(self, root_name), rest)
+            if attr in holder._parameters:
+                holder._parameters[attr].data = view
+                holder._parameters[attr].grad = None
+                names.append(m.name)
+            else:
+                holder._buffers[attr] = view
+        object.__setattr__(self, "_rln_param_names", names)
+        object.__setattr__(self, "_rln_param_set", set(names))
+        object.__setattr__(self, "_rln_param_offsets", {m.name: m.offset for m in eng.metas if m.kind == _lib.T_PARAM})
+        object.__setattr__(self, "_rln_dirty", False)
+        return eng
+
+    def _rln_params_in_arena_order(self) -> List[nn.Parameter]:
+        eng = self._rln_sync()
+        out = []
+        for name in self._rln_param_names:
+            root_name, rest = name.split(".", 1)
+            holder, attr = _resolve(getattr(self, root_name), rest)
+            out.append(holder._parameters[attr])
+        return out
+
+
+class TrainStepFn(torch.autograd.Function):
+    """loss = weighted CE(softmax probs) of the whole net; backward fills the flat gradient arena."""
+
+    @staticmethod
+    def forward(ctx, owner, x, y, drop_scales, seed, *params):
+        eng = owner._rln_sync()
+        probs, _ = eng.forward(x, training=True, with_backward=True, drop_scales=drop_scales, seed=seed)
+        out, _, _ = eng.loss(probs, y, weighted=True)
+        ctx.owner = owner
+        ctx.n_params = len(params)
+        loss = out[0].clone()
+        extra = out.detach()
+        ctx.mark_non_differentiable(extra, probs)
+        return loss, extra, probs
+
+    @staticmethod
+    def backward(ctx, g_loss, g_extra, g_probs):
+        owner = ctx.owner
+        eng = owner._rln_engine
+        eng.backward(1.0)
+        # hand autograd a private flat copy (AccumulateGrad may keep or add into these tensors), scaled by the
+        # incoming d(loss); FusedAdamW recognises the flat layout and consumes it with one kernel.
+        flat = eng.grads * g_loss
+        grads = []
+        for m in eng.metas:
+            if m.kind == _lib.T_PARAM and m.name in owner._rln_param_set:
+                grads.append(flat[m.offset:m.offset + m.numel].view(m.shape))
+        return (None, None, None, None, None) + tuple(grads)
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW semantics (single group, as SimpleTrain.py:28 configures it) executed by
+    one HIP kernel over the flat parameter / gradient / moment arenas."""
+
+    def __init__(self, owner: EngineOwner, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        self.owner = owner
+        params = owner._rln_params_in_arena_order()
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        eng = owner._rln_engine
+        self._step = 0
+        self.exp_avg = torch.zeros_like(eng.params)
+        self.exp_avg_sq = torch.zeros_like(eng.params)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        eng = self.owner._rln_sync()
+        if self.exp_avg.device != eng.params.device:
+            self.exp_avg = self.exp_avg.to(eng.params.device)
+            self.exp_avg_sq = self.exp_avg_sq.to(eng.params.device)
+        group = self.param_groups[0]
+        names = self.owner._rln_param_names
+        offs = self.owner._rln_param_offsets
+        params = group["params"]
+        # fast path: every .grad is a slice of ONE flat buffer in arena order (what TrainStepFn returns)
+        flat_ptr = None
+        g0 = params[0].grad
+        if g0 is not None and g0.dtype == torch.float32 and g0.device == eng.params.device:
+            base = g0.data_ptr() - 4 * offs[names[0]]
+            if all(p.grad is not None and p.grad.data_ptr() == base + 4 * offs[n] for p, n in zip(params, names)):
+                flat_ptr = base
+        if flat_ptr is None:
+            for p, name in zip(params, names):  # gradients from another autograd path: bring them into the arena
+                gv = eng.grad_views[name]
+                if p.grad is None:
+                    gv.zero_()
+                elif p.grad.data_ptr() != gv.data_ptr():
+                    gv.copy_(p.grad)
+            flat_ptr = eng.grads.data_ptr()
+        self._step += 1
+        eng.adamw_step_ptr(flat_ptr, self.exp_avg, self.exp_avg_sq, self._step, float(group["lr"]),
+                           tuple(group["betas"]), float(group["eps"]), float(group["weight_decay"]))
+        return loss
+
+    def state_dict(self):
+        d = super().state_dict()
+        d["rln"] = {"step": self._step, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq}
+        return d
+
+    def load_state_dict(self, state_dict):
+        extra = state_dict.get("rln")
+        super().load_state_dict({k: v for k, v in state_dict.items() if k != "rln"})
+        if extra is not None:
+            self._step = int(extra["step"])
+            self.exp_avg.copy_(extra["exp_avg"])
+            self.exp_avg_sq.copy_(extra["exp_avg_sq"])

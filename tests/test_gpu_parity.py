@@ -1,0 +1,286 @@
+"""End-to-end parity (-m gpu): the HIP path through the C ABI against (a) the golden vectors generated
+from the reference's own code and (b) the CPU oracle on the same seeded inputs.
+
+Tolerances (fp32 path, BASELINE.json north_star): argmax masks bit-exact (outside the near-tie pixels the
+fixture lists), probabilities / scaled logits within 1e-3 absolute, gradients within 1e-3 relative to the
+tensor's scale."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fcdensenet_oracle as O
+from tests.golden.common import cfg_from_arrays, sample_idx, synth_batch, unpack_masks
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    path = os.path.join(GOLDEN, name + ".npz")
+    if not os.path.exists(path):
+        pytest.skip(f"fixture {name} missing")
+    return np.load(path)
+
+
+def make_engine(cfg, st):
+    from sim2real_lane_segment_amd.engine import Engine, NetSpec
+    spec = NetSpec(in_channels=cfg.in_channels, down_blocks=cfg.down_blocks, up_blocks=cfg.up_blocks,
+                   bottleneck_layers=cfg.bottleneck_layers, growth_rate=cfg.growth_rate,
+                   out_chans_first_conv=cfg.out_chans_first_conv, n_classes=cfg.n_classes,
+                   temperature=cfg.temperature)
+    eng = Engine(spec, device="cuda")
+    eng.load_state(st)
+    return eng
+
+
+def rel_err(got, ref):
+    scale = max(float(np.abs(ref).max()), 1e-12)
+    return float(np.abs(got - ref).max()) / scale
+
+
+@pytest.mark.parametrize("name,full", [("tiny_40x56", True), ("tiny_33x47", True), ("g16_32x48", False),
+                                       ("g16_absent_30x34", False)])
+def test_small_nets_vs_golden(name, full):
+    z = load(name)
+    cfg = cfg_from_arrays(z, O.NetConfig)
+    n, h, w, seed = int(z["n"]), int(z["h"]), int(z["w"]), int(z["seed"])
+    st = O.init_state(cfg, seed)
+    x, y = synth_batch(n, h, w, cfg.n_classes, seed + 1)
+    if int(z["absent_class"]):
+        y[y == cfg.n_classes - 1] = 0
+    scales = O.make_drop_scales(cfg, n, seed + 2)
+    eng = make_engine(cfg, st)
+
+    # ---- eval forward ----
+    probs, feat = eng.forward(x.cuda(), training=False, want_feat=True)
+    logits, _ = eng.forward(x.cuda(), training=False, use_softmax=False)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(probs.cpu().numpy(), z["eval_probs"], atol=1e-3)
+    np.testing.assert_allclose(logits.cpu().numpy(), z["eval_logits"], atol=1e-3)
+    assert np.abs(probs.cpu().numpy() - z["eval_probs"]).max() < 2e-4  # what fp32 actually delivers
+    np.testing.assert_allclose(feat.sum((0, 2, 3)).cpu().numpy(), z["eval_feat_sum"], rtol=1e-3, atol=1e-3)
+    gap = np.sort(z["eval_logits"], axis=1)
+    clear = (gap[:, -1] - gap[:, -2]) > 2e-3
+    assert np.array_equal(probs.argmax(1).cpu().numpy()[clear], z["eval_probs"].argmax(1)[clear])
+
+    # ---- training step: forward, loss, backward, AdamW ----
+    ds = eng.pack_drop_scales(scales)
+    probs_t, _ = eng.forward(x.cuda(), training=True, with_backward=True, drop_scales=ds)
+    out, _, _ = eng.loss(probs_t, y.cuda(), weighted=True)
+    eng.backward(1.0)
+    torch.cuda.synchronize()
+    ref_pt = z["train_probs"]
+    got_pt = probs_t.cpu().numpy() if full else probs_t.cpu().numpy()[:, :, ::7, ::5]
+    np.testing.assert_allclose(got_pt, ref_pt, atol=1e-3)
+    assert abs(float(out[0]) - float(z["train_loss"])) < 1e-4
+    assert abs(float(out[1]) * 100 - float(z["train_acc"])) < 0.02
+    assert float(out[2]) == 0
+    # running statistics after the step
+    for k in z.files:
+        if k.startswith("buf1/"):
+            np.testing.assert_allclose(eng.views[k[5:]].cpu().numpy(), z[k], rtol=1e-4, atol=1e-5, err_msg=k)
+    for m in eng.metas:
+        if m.name.endswith("num_batches_tracked"):
+            assert int(eng.views[m.name]) == 1
+    bad = []
+    for m in eng.metas:
+        if m.kind != 0:
+            continue
+        g = eng.grad_views[m.name].cpu().numpy()
+        if full:
+            ref = z["grad/" + m.name]
+            err = rel_err(g, ref)
+        else:
+            idx = sample_idx(g.size, 64, 1234).numpy()
+            ref = z["gradsamp/" + m.name]
+            nrm = float(z["gradnorm/" + m.name])
+            e_samp = float(np.abs(g.reshape(-1)[idx] - ref).max()) / max(float(np.abs(ref).max()),
+                                                                         nrm / np.sqrt(g.size), 1e-12)
+            e_norm = abs(float(np.linalg.norm(g)) - nrm) / max(nrm, 1e-12)
+            err = max(e_samp / 3, e_norm)
+        if not err < 1e-3:
+            bad.append((m.name, err))
+    assert not bad, f"gradient mismatches (first in backward order last): {bad[:12]} ... total {len(bad)}"
+
+    m_buf = torch.zeros_like(eng.params)
+    v_buf = torch.zeros_like(eng.params)
+    eng.adamw_step(m_buf, v_buf, 1, 1e-3, weight_decay=1e-4)
+    torch.cuda.synchronize()
+    for m in eng.metas:
+        if m.kind != 0:
+            continue
+        p = eng.views[m.name].cpu().numpy()
+        if full:
+            np.testing.assert_allclose(p, z["param1/" + m.name], rtol=1e-3, atol=2e-5, err_msg=m.name)
+        else:
+            idx = sample_idx(p.size, 64, 1234).numpy()
+            np.testing.assert_allclose(p.reshape(-1)[idx], z["param1samp/" + m.name], rtol=1e-3, atol=2e-5,
+                                       err_msg=m.name)
+
+
+@pytest.mark.parametrize("name", ["fcd67_eval_120x160", "fcd67_eval_480x640"])
+def test_fcd67_eval_masks_vs_golden(name):
+    z = load(name)
+    cfg = cfg_from_arrays(z, O.NetConfig)
+    n, h, w, seed = int(z["n"]), int(z["h"]), int(z["w"]), int(z["seed"])
+    st = O.init_state(cfg, seed)
+    x, _ = synth_batch(n, h, w, 4, seed + 1)
+    eng = make_engine(cfg, st)
+    probs, feat = eng.forward(x.cuda(), training=False, want_feat=True)
+    logits, _ = eng.forward(x.cuda(), training=False, use_softmax=False)
+    out, am, _ = eng.loss(probs, torch.zeros(n, h, w, dtype=torch.int64).cuda(), weighted=False, want_argmax=True)
+    torch.cuda.synchronize()
+    mask = am.reshape(-1).cpu()
+    assert torch.equal(mask, probs.argmax(1).reshape(-1).cpu())
+    ref_mask = unpack_masks(z["mask_packed"], n * h * w)
+    near = set(int(i) for i in z["near_tie_idx"])
+    diff = torch.nonzero(mask != ref_mask).reshape(-1).tolist()
+    assert all(d in near for d in diff), f"{len(diff)} argmax flips, {sum(d not in near for d in diff)} outside near ties"
+    idx = torch.from_numpy(z["sample_idx"])
+    got_p = probs.permute(0, 2, 3, 1).reshape(-1, 4).cpu()[idx].numpy()
+    got_l = logits.permute(0, 2, 3, 1).reshape(-1, 4).cpu()[idx].numpy()
+    np.testing.assert_allclose(got_p, z["probs_samp"], atol=1e-3)
+    np.testing.assert_allclose(got_l, z["logits_samp"], atol=1e-3)
+    np.testing.assert_allclose(feat.double().sum((0, 2, 3)).cpu().numpy(), z["feat_sum"], rtol=1e-3, atol=2e-2)
+    iou_vs_ref = (mask == ref_mask).double().mean()
+    assert float(iou_vs_ref) > 1 - 1e-4
+
+
+def test_fcd67_train_steps_vs_golden():
+    z = load("fcd67_train_120x160")
+    cfg = cfg_from_arrays(z, O.NetConfig)
+    n, h, w, seed, steps = int(z["n"]), int(z["h"]), int(z["w"]), int(z["seed"]), int(z["steps"])
+    st = O.init_state(cfg, seed)
+    eng = make_engine(cfg, st)
+    m_buf = torch.zeros_like(eng.params)
+    v_buf = torch.zeros_like(eng.params)
+    for s in range(steps):
+        x, y = synth_batch(n, h, w, 4, seed + 10 * s + 1)
+        if s == 0:
+            y[0][y[0] == 3] = 0
+        scales = O.make_drop_scales(cfg, n, seed + 10 * s + 2)
+        probs, _ = eng.forward(x.cuda(), training=True, with_backward=True, drop_scales=eng.pack_drop_scales(scales))
+        out, _, _ = eng.loss(probs, y.cuda(), weighted=True)
+        eng.backward(1.0)
+        torch.cuda.synchronize()
+        assert abs(float(out[0]) - float(z["losses"][s])) < 2e-4, (s, float(out[0]), float(z["losses"][s]))
+        assert abs(float(out[1]) * 100 - float(z["accs"][s])) < 0.05
+        if s == 0:
+            bad = []
+            for m in eng.metas:
+                if m.kind != 0:
+                    continue
+                g = eng.grad_views[m.name].cpu().numpy()
+                nrm = float(z["gradnorm/" + m.name])
+                e1 = abs(float(np.linalg.norm(g)) - nrm) / max(nrm, 1e-12)
+                idx = sample_idx(g.size, 64, 1234).numpy()
+                e2 = float(np.abs(g.reshape(-1)[idx] - z["gradsamp/" + m.name]).max()) / max(
+                    float(np.abs(z["gradsamp/" + m.name]).max()), nrm / np.sqrt(g.size), 1e-12)
+                if not (e1 < 1e-3 and e2 < 5e-3):
+                    bad.append((m.name, e1, e2))
+            assert not bad, f"{len(bad)} gradient tensors off: {bad[:10]}"
+        eng.adamw_step(m_buf, v_buf, s + 1, 1e-3, weight_decay=1e-4)
+        if s == 0:
+            torch.cuda.synchronize()
+            for m in eng.metas:
+                if m.kind == 0:
+                    p = eng.views[m.name].cpu().numpy()
+                    idx = sample_idx(p.size, 64, 1234).numpy()
+                    np.testing.assert_allclose(p.reshape(-1)[idx], z["param1samp/" + m.name], rtol=1e-3, atol=3e-5,
+                                               err_msg=m.name)
+            for k in z.files:
+                if k.startswith("buf1/"):
+                    np.testing.assert_allclose(eng.views[k[5:]].cpu().numpy(), z[k], rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+def test_config0_batch8_train_step_vs_oracle():
+    """BASELINE.json configs[0]: batch 8, 120x160, one full training step against the CPU oracle run live."""
+    cfg = O.fcdensenet67_config(4)
+    st = O.init_state(cfg, 11)
+    n, h, w = 8, 120, 160
+    x, y = synth_batch(n, h, w, 4, 12)
+    scales = O.make_drop_scales(cfg, n, 13)
+    eng = make_engine(cfg, st)
+    probs, _ = eng.forward(x.cuda(), training=True, with_backward=True, drop_scales=eng.pack_drop_scales(scales))
+    out, _, _ = eng.loss(probs, y.cuda(), weighted=True)
+    eng.backward(1.0)
+    torch.cuda.synchronize()
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    ts = O.TrainState({k: v.clone() for k, v in st.items()})
+    loss, acc, grads, probs_ref = O.train_step(ts, x, y, cfg, scales, apply_update=False)
+    assert abs(float(out[0]) - float(loss)) < 2e-4
+    assert abs(float(out[1]) * 100 - float(acc)) < 0.05
+    np.testing.assert_allclose(probs.cpu().numpy(), probs_ref.numpy(), atol=1e-3)
+    bad = []
+    for k, g in grads.items():
+        got = eng.grad_views[k].cpu()
+        err = float((got - g).abs().max()) / max(float(g.abs().max()), 1e-12)
+        if not err < 2e-3:
+            bad.append((k, err))
+    assert not bad, f"{len(bad)} gradient tensors off: {bad[:10]}"
+
+
+def test_full_size_properties_batch64():
+    """BASELINE.json configs[1] size (batch 64, 120x160): size-independent properties."""
+    cfg = O.fcdensenet67_config(4)
+    st = O.init_state(cfg, 21)
+    eng = make_engine(cfg, st)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(64, 3, 120, 160, generator=g).cuda()
+    y = torch.randint(0, 4, (64, 120, 160), generator=g).cuda()
+    # eval forward is per-sample independent: a batch equals the concatenation of its halves, bit for bit
+    p_all, _ = eng.forward(x, training=False)
+    p_all = p_all.clone()
+    p_a, _ = eng.forward(x[:32].contiguous(), training=False)
+    p_a = p_a.clone()
+    p_b, _ = eng.forward(x[32:].contiguous(), training=False)
+    assert torch.equal(p_all[:32], p_a) and torch.equal(p_all[32:], p_b)
+    assert torch.allclose(p_all.sum(1), torch.ones_like(p_all[:, 0]), atol=1e-5)
+    # training step twice with the same seed: bitwise reproducible loss and gradients (no float atomics)
+    res = []
+    for _ in range(2):
+        eng.load_state(st)
+        probs, _ = eng.forward(x, training=True, with_backward=True, seed=77)
+        out, _, _ = eng.loss(probs, y, weighted=True)
+        eng.backward(1.0)
+        torch.cuda.synchronize()
+        res.append((out.clone(), eng.grads.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert torch.isfinite(res[0][1]).all() and float(res[0][1].abs().max()) > 0
+    # gradient linearity in loss_scale
+    eng.backward(2.0)
+    torch.cuda.synchronize()
+    assert torch.allclose(eng.grads, 2 * res[0][1], rtol=1e-5, atol=1e-12)
+
+
+def test_module_api_training_step_and_optimizer():
+    """The reference-shaped module: training_step -> loss.backward() -> FusedAdamW.step()."""
+    from sim2real_lane_segment_amd.trainingModules.SimpleTrain import RightLaneModule, SimpleTrainModule
+    assert RightLaneModule is SimpleTrainModule
+    torch.manual_seed(0)
+    model = SimpleTrainModule(lr=1e-3, lrRatio=1e3, decay=1e-4, num_cls=4).cuda()
+    model.train()
+    opt, sched = model.configure_optimizers()
+    x, y = synth_batch(2, 64, 96, 4, 3)
+    before = model.featureExtractor.firstconv.weight.detach().clone()
+    loss = model.training_step((x.cuda(), y.cuda()), 0, seed=1)
+    assert loss.requires_grad
+    loss.backward()
+    g = model.featureExtractor.firstconv.weight.grad
+    assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0
+    opt[0].step()
+    sched[0].step()
+    assert not torch.equal(before, model.featureExtractor.firstconv.weight.detach())
+    sd = model.state_dict()
+    assert len(sd) == 434
+    model.eval()
+    out = model(x.cuda())
+    assert out.shape == (2, 4, 64, 96)
+    ev = model.evaluate_batch((x.cuda(), y.cuda()))
+    assert set(ev) == {"loss", "acc", "dice", "iou", "weight"}
+    logs = model.summarize_evaluation_results([ev])
+    assert 0 <= float(logs["acc"]) <= 100
+    with pytest.raises(RuntimeError):
+        model(torch.zeros(1, 3, 16, 16).cuda())  # fewer than 32 px per side: five poolings do not fit
