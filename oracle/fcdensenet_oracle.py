@@ -301,7 +301,7 @@ def training_loss(probs: Tensor, y: Tensor, n_classes: int) -> Tuple[Tensor, Ten
     """SimpleTrainModule.training_step loss + accuracy (trainingModules/SimpleTrain.py:15-20):
     class-weighted cross_entropy applied to the softmax *probabilities* (double softmax),
     accuracy(argmax, y) * 100."""
-    loss = F.cross_entropy(probs, y, weight=get_class_weight(y, n_classes))
+    loss = F.cross_entropy(probs, y, weight=get_class_weight(y, n_classes).to(probs.dtype))
     labels_hat = torch.max(probs, 1)[1]
     acc = (labels_hat == y).float().mean() * 100
     return loss, acc

@@ -81,9 +81,9 @@ def test_conv1x1_pool(h, w, c):
     idx = torch.zeros(n, c, hp, wp, dtype=torch.uint8, device=dev)
     stats = torch.zeros(c, 2, device=dev)
     ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
-    L.check(lib.rln_op_conv_bnrelu(_p(x.to(dev)), n, c, c, 0, h, w, _p(a.to(dev)), _p(b.to(dev)), _p(wt.to(dev)),
-                                   _p(bias.to(dev)), c, 1, _p(scale.to(dev)), _p(out), c, 0, 1, _p(idx), _p(stats),
-                                   _p(ws), ws.numel(), _stream()))
+    xd, ad, bd, wd, biasd, sd = (t.to(dev) for t in (x, a, b, wt, bias, scale))  # keep alive across the launch
+    L.check(lib.rln_op_conv_bnrelu(_p(xd), n, c, c, 0, h, w, _p(ad), _p(bd), _p(wd), _p(biasd), c, 1, _p(sd), _p(out),
+                                   c, 0, 1, _p(idx), _p(stats), _p(ws), ws.numel(), _stream()))
     torch.cuda.synchronize()
     assert torch.allclose(out.cpu(), ref, atol=3e-5, rtol=1e-5)
     # argmax index: compare where the window has a unique maximum with a margin
@@ -110,8 +110,8 @@ def test_conv_transpose_crop(h, w, ho, wo, c):
     ref = F.conv_transpose2d(x, wt, bias, stride=2)[:, :, :ho, :wo]
     dev = "cuda"
     out = torch.full((n, out_ctot, ho, wo), 3.0, device=dev)
-    L.check(lib.rln_op_convt(_p(x.to(dev)), n, c, h, w, _p(wt.to(dev)), _p(bias.to(dev)), c, _p(out), out_ctot,
-                             out_coff, ho, wo, _stream()))
+    xd, wd, bd = x.to(dev), wt.to(dev), bias.to(dev)  # keep alive across the launch
+    L.check(lib.rln_op_convt(_p(xd), n, c, h, w, _p(wd), _p(bd), c, _p(out), out_ctot, out_coff, ho, wo, _stream()))
     torch.cuda.synchronize()
     got = out.cpu()
     assert torch.allclose(got[:, :c], ref, atol=3e-5, rtol=1e-5)
