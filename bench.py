@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training images/sec of FCDenseNet67 (num_cls=4) at per-GPU batch 64, 3x120x160
+synthetic Duckietown-like frames (BASELINE.json metric / configs[1]).
+
+One "step" = one full SimpleTrainModule training step on one batch already resident in HBM:
+forward (train-mode BatchNorm + Dropout2d) -> class-weighted CE on softmax probabilities -> backward ->
+AdamW, all in hand-written HIP (librln.so).  With N>1 (launched by torch.distributed.run, one process per
+GPU) gradients are averaged with bucketed RCCL all-reduce overlapped with backward; scaling is weak.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) including
+  "roofline":     achieved/peak of the dominant kernel class, timed live with HIP events on the launch stream,
+  "cpu_baseline": the CPU oracle's training step on the host cores (a bounded batch-8 sample).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_HBM_GBS = 8000.0
+TRAIN_FLOPS_PER_IMAGE = 47_718_689_280  # 3 x 15,906,229,760
+
+
+def read_profile(eng):
+    from sim2real_lane_segment_amd import _lib
+    L = _lib.lib()
+    k = L.rln_profile_num_classes()
+    ms = (ctypes.c_double * k)()
+    fl = (ctypes.c_double * k)()
+    by = (ctypes.c_double * k)()
+    ln = (ctypes.c_int64 * k)()
+    _lib.check(L.rln_profile_read(eng.ctx, ms, fl, by, ln), "rln_profile_read")
+    return [dict(name=L.rln_profile_class_name(i).decode(), ms=ms[i], flops=fl[i], bytes=by[i], launches=int(ln[i]))
+            for i in range(k)]
+
+
+def cpu_baseline(batch=8, timed_steps=2):
+    """The CPU oracle (a port of the reference step onto stock PyTorch CPU operators) on the host cores."""
+    from oracle import fcdensenet_oracle as O
+    from sim2real_lane_segment_amd.synthetic import make_batch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = O.fcdensenet67_config(4)
+    ts = O.TrainState(O.init_state(cfg, 0))
+    x, y = make_batch(batch, seed=42)
+    times = []
+    for s in range(1 + timed_steps):
+        scales = O.make_drop_scales(cfg, batch, 100 + s)
+        t0 = time.perf_counter()
+        O.train_step(ts, x, y, cfg, scales)
+        times.append(time.perf_counter() - t0)
+    t = sorted(times[1:])[len(times[1:]) // 2]
+    return {"value": round(batch / t, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{timed_steps} timed + 1 warm-up training steps (fwd+weighted CE+bwd+AdamW) at batch {batch}, "
+                      f"120x160, fp32, median"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (the metric is quoted at 64)")
+    ap.add_argument("--height", type=int, default=120)
+    ap.add_argument("--width", type=int, default=160)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--buckets", type=int, default=4)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    from sim2real_lane_segment_amd.synthetic import make_batch
+    from sim2real_lane_segment_amd.trainer import TrainStepper
+    from sim2real_lane_segment_amd.trainingModules.SimpleTrain import SimpleTrainModule
+
+    torch.manual_seed(42)
+    model = SimpleTrainModule(lr=1e-3, lrRatio=1e3, decay=1e-4, num_cls=4).to(dev)  # random init, FCDenseNet67
+    model.train()
+    eng = model._rln_sync()
+    stepper = TrainStepper(eng, lr=1e-3, weight_decay=1e-4, n_buckets=args.buckets)
+    stepper.broadcast_parameters()
+
+    B = args.batch
+    pool = [make_batch(B, args.height, args.width, seed=42, first_index=(rank * 4 + i) * B, device=dev)
+            for i in range(2)]
+    for i in range(args.warmup):
+        x, y = pool[i % len(pool)]
+        out = stepper.step(x, y)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    from sim2real_lane_segment_amd import _lib
+    if not args.no_profile:
+        _lib.check(_lib.lib().rln_profile_enable(eng.ctx, 1))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        x, y = pool[i % len(pool)]
+        out = stepper.step(x, y)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = float(out[0])
+    prof = None
+    if not args.no_profile:
+        prof = read_profile(eng)
+        _lib.check(_lib.lib().rln_profile_enable(eng.ctx, 0))
+
+    if rank == 0:
+        images = world * B * args.steps
+        result = {
+            "metric": "train images/sec @ batch 64, 3x120x160",
+            "value": round(images / elapsed, 2),
+            "unit": "images/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1000.0 * elapsed / args.steps, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"FCDenseNet67 num_cls=4 SimpleTrainModule training step (fwd+weighted CE+bwd+AdamW), "
+                                   f"per-GPU batch {B}, 3x{args.height}x{args.width} synthetic Duckietown frames, "
+                                   f"random-init weights, Dropout2d+BatchNorm in train mode",
+                       "global_batch": world * B, "parallelism": f"dp{world}", "final_loss": round(loss, 5)},
+        }
+        if prof is not None:
+            timed = [p for p in prof if p["launches"] > 0]
+            total_ms = sum(p["ms"] for p in timed)
+            dom = max((p for p in timed if p["flops"] > 0), key=lambda p: p["ms"])
+            ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+            result["roofline"] = {
+                "kernel": dom["name"], "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
+                "share_of_kernel_time": round(dom["ms"] / total_ms, 4),
+                "whole_step_tflops": round(TRAIN_FLOPS_PER_IMAGE * images / elapsed / 1e12, 3)
+                if (args.height, args.width) == (120, 160) else None,
+            }
+            result["kernel_classes"] = [
+                {"name": p["name"], "ms_per_step": round(p["ms"] / args.steps, 4),
+                 "launches_per_step": p["launches"] // args.steps,
+                 "tflops": round(p["flops"] / (p["ms"] * 1e-3) / 1e12, 2) if p["flops"] and p["ms"] else None,
+                 "alg_GBps": round(p["bytes"] / (p["ms"] * 1e-3) / 1e9, 1) if p["bytes"] and p["ms"] else None}
+                for p in sorted(timed, key=lambda p: -p["ms"])]
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

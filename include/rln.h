@@ -143,6 +143,15 @@ int rln_op_conv_bnrelu(const float* x, int n, int cin, int x_ctot, int x_coff, i
 int rln_op_convt(const float* x, int n, int cin, int h, int w, const float* weight, const float* bias, int cout,
                  float* out, int out_ctot, int out_coff, int hout, int wout, void* stream);
 
+/* ---- in-library timing: HIP events recorded on the launch stream around every kernel class --------------
+ * rln_profile_enable(ctx,1) clears and starts collecting, (ctx,0) stops.  rln_profile_read waits for the
+ * recorded events and returns, per kernel class, the summed device time (ms), the ALGORITHMIC flops and bytes
+ * of the launches (2*Cin*Cout*taps*H*W*N; each operand read once / result written once) and the launch count. */
+int rln_profile_enable(rln_ctx* ctx, int on);
+int rln_profile_num_classes(void);
+const char* rln_profile_class_name(int cls);
+int rln_profile_read(rln_ctx* ctx, double* ms, double* flops, double* bytes, int64_t* launches);
+
 /* rln_op_classifier: FCDenseNetClassifier.forward on caller-provided weights (tiramisu.py:120-125):
  * out[n,k,p] = softmax_k((sum_c w[k,c]*feat[n,c,p] + b[k]) / T). */
 int rln_op_classifier(const float* feat, int n, int c, int hw, const float* w, const float* b, int ncls, float T,

@@ -58,6 +58,11 @@ _PROTOS = {
                                    c_void_p, c_void_p, c_size_t, c_void_p]),
     "rln_op_convt": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
                              c_int, c_int, c_void_p]),
+    "rln_profile_enable": (c_int, [c_void_p, c_int]),
+    "rln_profile_num_classes": (c_int, []),
+    "rln_profile_class_name": (c_char_p, [c_int]),
+    "rln_profile_read": (c_int, [c_void_p, POINTER(ctypes.c_double), POINTER(ctypes.c_double),
+                                 POINTER(ctypes.c_double), POINTER(c_int64)]),
     "rln_op_classifier": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_int,
                                   c_void_p]),
 }

@@ -81,7 +81,38 @@ struct Level {
 
 }  // namespace
 
+enum ProfClass {
+  PC_DENSE_FWD = 0, PC_FIRST_FWD, PC_TD_FWD, PC_TU_FWD, PC_DENSE_DGRAD, PC_TD_DGRAD, PC_TU_DGRAD, PC_DENSE_WGRAD,
+  PC_FIRST_WGRAD, PC_TD_WGRAD, PC_TU_WGRAD, PC_BN, PC_GRADFIN, PC_REDUCE, PC_HEAD_FWD, PC_LOSS, PC_HEAD_BWD, PC_COUNT
+};
+static const char* kProfNames[PC_COUNT] = {
+    "dense_conv3x3_fwd", "first_conv_fwd", "transition_down_fwd", "transition_up_fwd", "dense_conv3x3_dgrad",
+    "transition_down_dgrad", "transition_up_dgrad", "dense_conv3x3_wgrad", "first_conv_wgrad",
+    "transition_down_wgrad", "transition_up_wgrad", "bn_stats_affine", "grad_finalize", "partial_reduce",
+    "head_fwd", "loss", "head_bwd"};
+struct ProfEntry {
+  hipEvent_t a, b;
+  int cls;
+  double flops, bytes;
+};
+struct Profiler {
+  bool on = false;
+  std::vector<ProfEntry> entries;
+  std::vector<hipEvent_t> pool;
+  hipEvent_t get() {
+    if (!pool.empty()) {
+      hipEvent_t e = pool.back();
+      pool.pop_back();
+      return e;
+    }
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+  }
+};
+
 struct rln_ctx {
+  Profiler prof;
   rln_config cfg;
   std::vector<TensorInfo> tensors;
   std::vector<Op> ops;
@@ -506,6 +537,29 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+// Brackets one launch (or a small group) with HIP events on the launch stream when profiling is on.
+struct ProfScope {
+  rln_ctx* c;
+  hipStream_t s;
+  int idx = -1;
+  ProfScope(rln_ctx* c_, int cls, double flops, double bytes, hipStream_t s_) : c(c_), s(s_) {
+    if (!c->prof.on) return;
+    ProfEntry e;
+    e.a = c->prof.get();
+    e.b = c->prof.get();
+    e.cls = cls;
+    e.flops = flops;
+    e.bytes = bytes;
+    if (!e.a || !e.b) return;
+    (void)hipEventRecord(e.a, s);
+    c->prof.entries.push_back(e);
+    idx = (int)c->prof.entries.size() - 1;
+  }
+  ~ProfScope() {
+    if (idx >= 0) (void)hipEventRecord(c->prof.entries[idx].b, s);
+  }
+};
+
 // ---------------------------------------------------------------------------------------------
 // forward ops
 // ---------------------------------------------------------------------------------------------
@@ -514,6 +568,7 @@ int finalize_stats(rln_ctx* c, int level, int ch_off, int J, long long nblk, hip
   const Level& lv = c->levels[level];
   const double count = (double)c->N * lv.H * lv.W;
   const int64_t so = lv.stat_off + ch_off;
+  ProfScope ps(c, PC_BN, 0, 0, s);
   RLN_TRY(bn_finalize(c->stat_partial, nblk, J, count, c->cfg.bn_eps, c->mean + so, c->var + so, c->invstd + so,
                       c->stdv + so, s));
   return 0;
@@ -523,6 +578,7 @@ int prep_bn(rln_ctx* c, const Op& o, int training, hipStream_t s) {
   const Level& lv = c->levels[o.src_level];
   const int64_t so = lv.stat_off + o.in_off;
   const double count = (double)c->N * lv.H * lv.W;
+  ProfScope ps(c, PC_BN, 0, 0, s);
   RLN_TRY(bn_prep(training, o.bn.C, c->params + o.bn.gamma, c->params + o.bn.beta, c->mean + so, c->var + so,
                   c->invstd + so, c->bnrun + o.bn.rmean, c->bnrun + o.bn.rvar, c->cfg.bn_momentum, count,
                   c->cfg.bn_eps, c->ab + o.bn.ab, c->ab + c->n_ab + o.bn.ab, s));
@@ -612,7 +668,15 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
   p.tiles_y = (p.GH + th - 1) / th;
   p.tiles_x = (p.GW + tw - 1) / tw;
   p.out_vec = (p.ncls == 1 && (p.Wout % 4) == 0 && aligned16(p.out)) ? 1 : 0;
-  RLN_TRY(igemm_launch(kind, tile, p, N, s));
+  {
+    const double taps = (o.type == OP_TD) ? 1.0 : 9.0;
+    const double flops = 2.0 * o.cin * o.cout * taps * p.Hin * p.Win * N;  // convT counted on its input grid
+    const double bytes = 4.0 * N * ((double)o.cin * p.Hin * p.Win + (double)o.cout * p.Hout * p.Wout);
+    const int cls = o.type == OP_FIRST ? PC_FIRST_FWD : o.type == OP_DENSE ? PC_DENSE_FWD
+                    : o.type == OP_TD  ? PC_TD_FWD : PC_TU_FWD;
+    ProfScope ps(c, cls, flops, bytes, s);
+    RLN_TRY(igemm_launch(kind, tile, p, N, s));
+  }
   if (training) RLN_TRY(finalize_stats(c, o.dst_level, o.out_off, o.cout, igemm_stat_blocks(p, N), s));
   return 0;
 }
@@ -658,11 +722,17 @@ int finalize_grad_range(rln_ctx* c, int level, int ch_off, int C, const float* n
   g.bias_partial = c->bpartial;
   g.Hd = lv.H;
   g.Wd = lv.W;
+  ProfScope ps(c, PC_GRADFIN, 0, 12.0 * c->N * C * plane, s);
   RLN_TRY(grad_finalize(g, c->N, rows, s));
   return 0;
 }
 
 int run_wgrad(rln_ctx* c, WgradKind kind, WgradParams& w, int Mc, int Nc, int64_t grad_off, hipStream_t s) {
+  const int pcls = kind == WG_DENSE3 ? PC_DENSE_WGRAD : kind == WG_RAW3 ? PC_FIRST_WGRAD
+                   : kind == WG_PW1  ? PC_TD_WGRAD : PC_TU_WGRAD;
+  const double taps = (kind == WG_PW1) ? 1.0 : 9.0;
+  const double wflops = 2.0 * Mc * Nc * taps * w.GH * w.GW * c->N;
+  const double wbytes = 4.0 * c->N * ((double)w.Uc * w.GH * w.GW + (double)w.Vc * w.Hv * w.Wv);
   const int tile = wgrad_pick_tile(w.GH, w.GW);
   int th, tw, mpb, npb;
   wgrad_tile_dims(kind, tile, &th, &tw);
@@ -676,7 +746,11 @@ int run_wgrad(rln_ctx* c, WgradKind kind, WgradParams& w, int Mc, int Nc, int64_
   w.items_per_chunk = ipc;
   w.nchunks = (int)nch;
   w.partial = c->wpartial;
-  RLN_TRY(wgrad_launch(kind, tile, w, s));
+  {
+    ProfScope ps(c, pcls, wflops, wbytes, s);
+    RLN_TRY(wgrad_launch(kind, tile, w, s));
+  }
+  ProfScope ps2(c, PC_REDUCE, 0, 4.0 * (nch + 1) * w.wsize, s);
   RLN_TRY(reduce_rows(c->wpartial, nch, w.wsize, c->grads + grad_off, s));
   return 0;
 }
@@ -730,7 +804,13 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
       p.tiles_y = (p.GH + th - 1) / th;
       p.tiles_x = (p.GW + tw - 1) / tw;
       p.out_vec = ((lv.W % 4) == 0 && aligned16(p.out) && aligned16(p.S)) ? 1 : 0;
-      RLN_TRY(igemm_launch(IG_DGRAD3, tile, p, N, s));
+      {
+        const double flops = 2.0 * o.cin * o.cout * 9.0 * plane * N;
+        const double bytes = 4.0 * N * plane * ((double)o.cout + 2.0 * o.cin + (double)(o.acc_hi - o.acc_lo));
+        ProfScope ps(c, PC_DENSE_DGRAD, flops, bytes, s);
+        RLN_TRY(igemm_launch(IG_DGRAD3, tile, p, N, s));
+      }
+      ProfScope psb(c, PC_BN, 0, 0, s);
       RLN_TRY(bn_bwd_finalize(c->stat_partial, igemm_stat_blocks(p, N), o.cin, c->params + o.bn.gamma,
                               c->grads + o.bn.gamma, c->grads + o.bn.beta, c->S1 + so, c->S2 + so, s));
     }
@@ -785,6 +865,7 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
       g.pool_idx = c->pool_idx + c->pool_off[k];
       g.Hd = sl.H;
       g.Wd = sl.W;
+      ProfScope ps(c, PC_GRADFIN, 0, 4.0 * N * o.cout * (splane + 2.25 * dplane), s);
       RLN_TRY(grad_finalize(g, N, &rows, s));
       RLN_TRY(reduce_rows(c->bpartial, rows, o.cout, c->grads + o.conv.b, s));
     }
@@ -826,7 +907,12 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
     p.tiles_y = (p.GH + th - 1) / th;
     p.tiles_x = (p.GW + tw - 1) / tw;
     p.out_vec = ((sl.W % 4) == 0 && aligned16(p.out) && aligned16(p.S)) ? 1 : 0;
-    RLN_TRY(igemm_launch(IG_DGRAD1, tile, p, N, s));
+    {
+      const double flops = 2.0 * o.cin * o.cout * splane * N;
+      const double bytes = 4.0 * N * splane * ((double)o.cout + 3.0 * o.cin);
+      ProfScope ps(c, PC_TD_DGRAD, flops, bytes, s);
+      RLN_TRY(igemm_launch(IG_DGRAD1, tile, p, N, s));
+    }
     RLN_TRY(bn_bwd_finalize(c->stat_partial, igemm_stat_blocks(p, N), o.cin, c->params + o.bn.gamma,
                             c->grads + o.bn.gamma, c->grads + o.bn.beta, c->S1 + so, c->S2 + so, s));
     WgradParams w;
@@ -883,7 +969,12 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
     p.tiles_y = (p.GH + th - 1) / th;
     p.tiles_x = (p.GW + tw - 1) / tw;
     p.out_vec = ((sl.W % 4) == 0 && aligned16(p.out)) ? 1 : 0;
-    RLN_TRY(igemm_launch(IG_S2D3, tile, p, N, s));
+    {
+      const double flops = 2.0 * o.cin * o.cout * 9.0 * splane * N;
+      const double bytes = 4.0 * N * ((double)o.cout * dplane + (double)o.cin * splane);
+      ProfScope ps(c, PC_TU_DGRAD, flops, bytes, s);
+      RLN_TRY(igemm_launch(IG_S2D3, tile, p, N, s));
+    }
     WgradParams w;
     memset(&w, 0, sizeof(w));
     w.u = sl.S + (size_t)o.in_off * splane;  // convT input (raw)
@@ -1010,6 +1101,8 @@ int rln_forward(rln_ctx* c, const float* x, int n, int h, int w, int training, c
   for (size_t k = 0; k < c->ops.size(); ++k) RLN_TRY(fwd_op(c, k, x, training, s));
   if (probs_out || feat_out) {
     HeadParams hp = head_params(c);
+    ProfScope ps(c, PC_HEAD_FWD, 2.0 * n * hp.HW * hp.C * (hp.ncls + 1),
+                 4.0 * n * hp.HW * (hp.C + hp.ncls + (feat_out ? 2.0 * hp.C : 0.0)), s);
     RLN_TRY(head_forward(hp, n, probs_out, use_softmax, feat_out, s));
   }
   c->last_x = x;
@@ -1038,8 +1131,11 @@ int rln_loss(rln_ctx* c, const float* probs, const int64_t* y, int n, int h, int
              int64_t* argmax_out, int64_t* confusion_out, void* stream) {
   if (!c->loss.counts || n != c->N || h != c->H || w != c->W)
     return fail(RLN_ERR_WORKSPACE, "workspace not set for geometry %dx%dx%d", n, h, w);
-  RLN_TRY(loss_forward(probs, (const long long*)y, n, c->cfg.n_classes, h * w, weighted, c->loss, out,
-                       (long long*)argmax_out, (long long*)confusion_out, (hipStream_t)stream));
+  {
+    ProfScope ps(c, PC_LOSS, 0, (4.0 * c->cfg.n_classes + 16.0) * n * h * w, (hipStream_t)stream);
+    RLN_TRY(loss_forward(probs, (const long long*)y, n, c->cfg.n_classes, h * w, weighted, c->loss, out,
+                         (long long*)argmax_out, (long long*)confusion_out, (hipStream_t)stream));
+  }
   c->last_y = y;
   c->have_loss = weighted ? 1 : 0;
   return 0;
@@ -1075,6 +1171,7 @@ int rln_backward(rln_ctx* c, float loss_scale, int seg_begin, int seg_end, void*
     q.glin = c->glin;
     q.bias_partial = c->bpartial;
     long long rows = 0;
+    ProfScope ps(c, PC_HEAD_BWD, 2.0 * N * q.h.HW * q.h.C * (3.0 * q.h.ncls + 2), 4.0 * N * q.h.HW * 4.0 * q.h.C, s);
     RLN_TRY(head_backward_data(q, N, &rows, s));
     RLN_TRY(reduce_rows(c->bpartial, rows, c->cfg.n_classes, c->grads + c->cls.b, s));
     RLN_TRY(head_backward_weight(q.h, N, c->glin, c->wpartial, s));
@@ -1172,6 +1269,40 @@ int rln_op_convt(const float* x, int n, int cin, int h, int w, const float* weig
   p.tiles_y = (p.GH + th - 1) / th;
   p.tiles_x = (p.GW + tw - 1) / tw;
   RLN_TRY(igemm_launch(IG_CONV3_RAW, tile, p, n, (hipStream_t)stream));
+  return 0;
+}
+
+int rln_profile_enable(rln_ctx* c, int on) {
+  for (ProfEntry& e : c->prof.entries) {
+    c->prof.pool.push_back(e.a);
+    c->prof.pool.push_back(e.b);
+  }
+  c->prof.entries.clear();
+  c->prof.on = on != 0;
+  return 0;
+}
+
+int rln_profile_num_classes(void) { return PC_COUNT; }
+const char* rln_profile_class_name(int cls) { return (cls >= 0 && cls < PC_COUNT) ? kProfNames[cls] : ""; }
+
+int rln_profile_read(rln_ctx* c, double* ms, double* flops, double* bytes, int64_t* launches) {
+  for (int i = 0; i < PC_COUNT; ++i) {
+    ms[i] = 0;
+    flops[i] = 0;
+    bytes[i] = 0;
+    launches[i] = 0;
+  }
+  for (ProfEntry& e : c->prof.entries) {
+    hipError_t err = hipEventSynchronize(e.b);
+    if (err != hipSuccess) return fail((int)err, "hipEventSynchronize failed");
+    float t = 0.f;
+    err = hipEventElapsedTime(&t, e.a, e.b);
+    if (err != hipSuccess) return fail((int)err, "hipEventElapsedTime failed");
+    ms[e.cls] += t;
+    flops[e.cls] += e.flops;
+    bytes[e.cls] += e.bytes;
+    launches[e.cls] += 1;
+  }
   return 0;
 }
 
