@@ -42,7 +42,30 @@ struct IgCfg {
   }
 };
 
-template <int KS, int NT, int PRO, int EPI, int TH, int TW>
+// Straight-line MFMA block for one staged 16-channel chunk: every LDS offset is a compile-time constant relative
+// to one per-lane base, so reads shared by several (M-tile, tap) pairs are issued once and carry immediates.
+template <typename C, int NT, int TW, unsigned MASK>
+__device__ __forceinline__ void igemm_compute(const float* __restrict__ zbase, const float* __restrict__ wlane,
+                                              f32x4 (&acc)[C::MPW][NT]) {
+#pragma unroll
+  for (int kg = 0; kg < 4; ++kg) {
+#pragma unroll
+    for (int s = 0; s < C::NS; ++s) {
+      if (!((MASK >> s) & 1u)) continue;
+      float bw[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bw[nt] = wlane[((kg * C::NS + s) * NT + nt) * 64];
+#pragma unroll
+      for (int m = 0; m < C::MPW; ++m) {
+        const float a = zbase[kg * 4 * C::CHS + ((m * 16) / TW) * C::PITCH + (m * 16) % TW + C::slot_off(s)];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mfma16(a, bw[nt], acc[m][nt]);
+      }
+    }
+  }
+}
+
+template <int KS, int NT, int PRO, int EPI, int TH, int TW, bool CLS>
 __global__ __launch_bounds__(256) void igemm_k(const IgemmParams p) {
   using C = IgCfg<KS, NT, PRO, EPI, TH, TW>;
   constexpr int MPW = C::MPW;
@@ -57,7 +80,7 @@ __global__ __launch_bounds__(256) void igemm_k(const IgemmParams p) {
   int bx = blockIdx.x;
   const int tiles = p.tiles_x * p.tiles_y;
   int cls = 0;
-  if (p.ncls > 1) {
+  if constexpr (CLS) {
     cls = bx / tiles;
     bx -= cls * tiles;
   }
@@ -90,20 +113,9 @@ __global__ __launch_bounds__(256) void igemm_k(const IgemmParams p) {
       if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) goff[i] = iy * p.Win + ix;
     }
   }
-  int pixoff[MPW];
-#pragma unroll
-  for (int m = 0; m < MPW; ++m) {
-    const int q0 = (wave * MPW + m) * 16;
-    const int ty = q0 / TW, tx = q0 - ty * TW;
-    pixoff[m] = ty * C::PITCH + tx + lj;
-  }
-  unsigned smask = (1u << C::NS) - 1u;
-  if (p.tapmode == TM_CONVT) {
-    smask = 0;
-    for (int sy = 0; sy < 2; ++sy)
-      for (int sx = 0; sx < 2; ++sx)
-        if ((sy == 1 || py == 0) && (sx == 1 || px == 0)) smask |= 1u << (sy * 3 + sx);
-  }
+  static_assert((MPW * 16) % TW == 0, "a wave's M-tiles must start on a tile row");
+  const float* zbase = zl + lk * C::CHS + ((wave * MPW * 16) / TW) * C::PITCH + lj;
+  const float* wlane = wl + lane;
 
   f32x4 acc[MPW][NT];
 #pragma unroll
@@ -166,34 +178,23 @@ __global__ __launch_bounds__(256) void igemm_k(const IgemmParams p) {
       }
     }
     __syncthreads();
-    // ---- MFMA ----
-    const int kgn = min(4, (p.K - c0 + 3) >> 2);
-#pragma unroll
-    for (int kg = 0; kg < 4; ++kg) {
-      if (kg < kgn) {
-        const float* zb = zl + (kg * 4 + lk) * C::CHS;
-#pragma unroll
-        for (int s = 0; s < C::NS; ++s) {
-          if ((smask >> s) & 1u) {
-            float bw[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bw[nt] = wl[((kg * C::NS + s) * NT + nt) * 64 + lane];
-#pragma unroll
-            for (int m = 0; m < MPW; ++m) {
-              const float a = zb[pixoff[m] + C::slot_off(s)];
-#pragma unroll
-              for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mfma16(a, bw[nt], acc[m][nt]);
-            }
-          }
-        }
+    // ---- MFMA (channels past K are zero-filled in LDS, so all four 4-channel groups always run) ----
+    if constexpr (CLS) {  // ConvTranspose2d output parity class: only the taps with matching parity exist
+      switch (cls) {
+        case 0: igemm_compute<C, NT, TW, 0x1Bu>(zbase, wlane, acc); break;
+        case 1: igemm_compute<C, NT, TW, 0x12u>(zbase, wlane, acc); break;
+        case 2: igemm_compute<C, NT, TW, 0x18u>(zbase, wlane, acc); break;
+        default: igemm_compute<C, NT, TW, 0x10u>(zbase, wlane, acc); break;
       }
+    } else {
+      igemm_compute<C, NT, TW, (1u << C::NS) - 1u>(zbase, wlane, acc);
     }
   }
 
   const long long blk_lin = (long long)n * gridDim.x + blockIdx.x;
 
   if constexpr (EPI == EPI_STORE || EPI == EPI_DGRAD) {
-    const int S_ = (p.ncls > 1) ? 2 : 1;
+    constexpr int S_ = CLS ? 2 : 1;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int j = jbase + nt * 16 + lj;
@@ -370,11 +371,12 @@ __global__ __launch_bounds__(256) void igemm_k(const IgemmParams p) {
   }
 }
 
-template <int KS, int NT, int PRO, int EPI, int TH, int TW>
+template <int KS, int NT, int PRO, int EPI, int TH, int TW, bool CLS = false>
 static int launch_t(const IgemmParams& p, int N, hipStream_t stream) {
   using C = IgCfg<KS, NT, PRO, EPI, TH, TW>;
   static bool attr_done = false;
-  auto kern = igemm_k<KS, NT, PRO, EPI, TH, TW>;
+  auto kern = igemm_k<KS, NT, PRO, EPI, TH, TW, CLS>;
+  if ((p.ncls > 1) != CLS) return -1;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               C::LDS_BYTES);
@@ -412,6 +414,9 @@ int igemm_launch(IgemmKind kind, int tile, const IgemmParams& p, int N, hipStrea
       return tile == 0 ? launch_t<3, 1, PRO_BNRELU, EPI_STORE, 8, 32>(p, N, stream)
                        : launch_t<3, 1, PRO_BNRELU, EPI_STORE, 16, 16>(p, N, stream);
     case IG_CONV3_RAW:
+      if (p.ncls > 1)
+        return tile == 0 ? launch_t<3, 1, PRO_RAW, EPI_STORE, 8, 32, true>(p, N, stream)
+                         : launch_t<3, 1, PRO_RAW, EPI_STORE, 16, 16, true>(p, N, stream);
       return tile == 0 ? launch_t<3, 1, PRO_RAW, EPI_STORE, 8, 32>(p, N, stream)
                        : launch_t<3, 1, PRO_RAW, EPI_STORE, 16, 16>(p, N, stream);
     case IG_CONV1_POOL:
@@ -561,30 +566,37 @@ __global__ __launch_bounds__(256) void wgrad_k(const WgradParams p) {
       }
     }
     __syncthreads();
-    // ---- MFMA over the tile's pixels, 4 consecutive x per k-step ----
-#pragma unroll 2
-    for (int ks = 0; ks < TH * TW / 4; ++ks) {
-      const int ty = ks / (TW / 4), tx0 = (ks - ty * (TW / 4)) * 4;
-      const int upix = ty * TW + tx0 + lk;
-      const int vpix = ty * C::PITCH + tx0 + lk;
-      if constexpr (!SHIFT_A) {
-        float a[MT];
+    // ---- MFMA over the tile's pixels, 4 consecutive x per k-step; straight-line, constexpr LDS offsets ----
+    {
+      const float* ubase = ul + lj * C::UST + lk;
+      const float* vbase = vl + lj * C::VST + lk;
+      const float* uw = ubase + (SHIFT_A ? wave * 16 * C::UST : 0);
+      const float* vw = vbase + (SHIFT_A ? 0 : wave * 16 * C::VST);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[mt] = ul[(mt * 16 + lj) * C::UST + upix];
+      for (int ks = 0; ks < TH * TW / 4; ++ks) {
+        constexpr int KPR = TW / 4;
+        const int ty = ks / KPR, tx0 = (ks % KPR) * 4;
+        const int upix = ty * TW + tx0;
+        const int vpix = ty * C::PITCH + tx0;
+        if constexpr (!SHIFT_A) {
+          float a[MT];
 #pragma unroll
-        for (int s = 0; s < C::NS; ++s) {
-          const float b = vl[(wave * 16 + lj) * C::VST + C::slot_off(s) + vpix];
+          for (int mt = 0; mt < MT; ++mt) a[mt] = uw[mt * 16 * C::UST + upix];
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) acc[mt][s] = mfma16(a[mt], b, acc[mt][s]);
-        }
-      } else {
-        const float b = ul[(wave * 16 + lj) * C::UST + upix];
+          for (int s = 0; s < C::NS; ++s) {
+            const float b = vw[C::slot_off(s) + vpix];
 #pragma unroll
-        for (int s = 0; s < C::NS; ++s) {
+            for (int mt = 0; mt < MT; ++mt) acc[mt][s] = mfma16(a[mt], b, acc[mt][s]);
+          }
+        } else {
+          const float b = uw[upix];
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            const float a = vl[(mt * 16 + lj) * C::VST + C::slot_off(s) + vpix];
-            acc[mt][s] = mfma16(a, b, acc[mt][s]);
+          for (int s = 0; s < C::NS; ++s) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              const float a = vw[mt * 16 * C::VST + C::slot_off(s) + vpix];
+              acc[mt][s] = mfma16(a, b, acc[mt][s]);
+            }
           }
         }
       }

