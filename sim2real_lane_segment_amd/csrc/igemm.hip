@@ -47,17 +47,20 @@ struct IgCfg {
 template <typename C, int NT, int TW, unsigned MASK>
 __device__ __forceinline__ void igemm_compute(const float* __restrict__ zbase, const float* __restrict__ wlane,
                                               f32x4 (&acc)[C::MPW][NT]) {
-#pragma unroll
+  // one 4-channel group per (rolled) iteration keeps the live LDS fragments small; inside, straight-line code
+#pragma unroll 1
   for (int kg = 0; kg < 4; ++kg) {
+    const float* zk = zbase + kg * 4 * C::CHS;
+    const float* wk = wlane + kg * C::NS * NT * 64;
 #pragma unroll
     for (int s = 0; s < C::NS; ++s) {
       if (!((MASK >> s) & 1u)) continue;
       float bw[NT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bw[nt] = wlane[((kg * C::NS + s) * NT + nt) * 64];
+      for (int nt = 0; nt < NT; ++nt) bw[nt] = wk[(s * NT + nt) * 64];
 #pragma unroll
       for (int m = 0; m < C::MPW; ++m) {
-        const float a = zbase[kg * 4 * C::CHS + ((m * 16) / TW) * C::PITCH + (m * 16) % TW + C::slot_off(s)];
+        const float a = zk[((m * 16) / TW) * C::PITCH + (m * 16) % TW + C::slot_off(s)];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mfma16(a, bw[nt], acc[m][nt]);
       }
@@ -66,7 +69,7 @@ __device__ __forceinline__ void igemm_compute(const float* __restrict__ zbase, c
 }
 
 template <int KS, int NT, int PRO, int EPI, int TH, int TW, bool CLS>
-__global__ __launch_bounds__(256) void igemm_k(const IgemmParams p) {
+__global__ __launch_bounds__(256, (NT == 1 ? 4 : 2)) void igemm_k(const IgemmParams p) {
   using C = IgCfg<KS, NT, PRO, EPI, TH, TW>;
   constexpr int MPW = C::MPW;
   static_assert(TW % 16 == 0 && (TH * TW) % 64 == 0, "tile must be whole M-tiles per wave");
@@ -125,15 +128,55 @@ __global__ __launch_bounds__(256) void igemm_k(const IgemmParams p) {
 
   const float* in_n = p.in + (long long)n * p.in_ns;
   const int nchunk = (p.K + 15) >> 4;
-  for (int ch = 0; ch < nchunk; ++ch) {
+
+  // Register-staged software pipeline: the global loads of chunk ch+1 are issued BEFORE the MFMA phase of
+  // chunk ch and committed (activation applied, written to LDS) after it, so HBM/L2 latency hides under MFMA.
+  float rin[16][C::NPOS];
+  float rwt[C::NWE];
+  auto weight_index = [&](int e, int c0, int& lidx) -> long long {
+    const int s = e % C::NS, t = e / C::NS;
+    const int cc = t & 15, jj = t >> 4;
+    const int j = jbase + jj, k = c0 + cc;
+    int tap;
+    if (p.tapmode == TM_ID) {
+      tap = s;
+    } else if (p.tapmode == TM_FLIP) {
+      tap = C::NS - 1 - s;
+    } else {
+      const int sy = s / 3, sx = s - sy * 3;
+      const int ky = (sy == 1) ? py : ((sy == 0 && py == 0) ? 2 : -1);
+      const int kx = (sx == 1) ? px : ((sx == 0 && px == 0) ? 2 : -1);
+      tap = (ky < 0 || kx < 0) ? -1 : ky * 3 + kx;
+    }
+    lidx = (((cc >> 2) * C::NS + s) * NT + (jj >> 4)) * 64 + (cc & 3) * 16 + (jj & 15);
+    return (j < p.J && k < p.K && tap >= 0) ? ((long long)j * p.w_js + (long long)k * p.w_ks + tap) : -1;
+  };
+  auto issue = [&](int ch) {
     const int c0 = ch * 16;
-    if (ch > 0) __syncthreads();
-    // ---- stage 16 input channels (tile + halo), activation applied on the way ----
-#pragma unroll 4
+#pragma unroll
     for (int cc = 0; cc < 16; ++cc) {
       const int c = c0 + cc;
       const bool cv = c < p.K;
       const float* src = in_n + (long long)c * p.in_cs;
+#pragma unroll
+      for (int i = 0; i < C::NPOS; ++i) rin[cc][i] = (cv && goff[i] >= 0) ? src[goff[i]] : 0.f;
+    }
+    int tid_o = tid;
+    asm volatile("" : "+v"(tid_o));  // opaque: recompute the cheap decode per chunk instead of hoisting it
+#pragma unroll
+    for (int i = 0; i < C::NWE; ++i) {
+      const int e = tid_o + 256 * i;
+      int lidx;
+      const long long gi = (e < C::WE) ? weight_index(e, c0, lidx) : -1;
+      rwt[i] = (gi >= 0) ? p.w[gi] : 0.f;
+    }
+  };
+  auto commit = [&](int ch) {
+    const int c0 = ch * 16;
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) {
+      const int c = c0 + cc;
+      const bool cv = c < p.K;
       float a = 1.f, b = 0.f;
       if constexpr (PRO == PRO_BNRELU) {
         if (cv) {
@@ -144,40 +187,31 @@ __global__ __launch_bounds__(256) void igemm_k(const IgemmParams p) {
 #pragma unroll
       for (int i = 0; i < C::NPOS; ++i) {
         if (loff[i] >= 0) {
-          float v = 0.f;
-          if (cv && goff[i] >= 0) {
-            v = src[goff[i]];
-            if constexpr (PRO == PRO_BNRELU) v = fmaxf(fmaf(a, v, b), 0.f);
-          }
+          float v = rin[cc][i];
+          if constexpr (PRO == PRO_BNRELU) v = (cv && goff[i] >= 0) ? fmaxf(fmaf(a, v, b), 0.f) : 0.f;
           zl[cc * C::CHS + loff[i]] = v;
         }
       }
     }
-    // ---- stage the weight slab in B-operand order ----
-#pragma unroll 4
+    int tid_o = tid;
+    asm volatile("" : "+v"(tid_o));
+#pragma unroll
     for (int i = 0; i < C::NWE; ++i) {
-      const int e = tid + 256 * i;
+      const int e = tid_o + 256 * i;
       if (e < C::WE) {
-        const int s = e % C::NS, t = e / C::NS;
-        const int cc = t & 15, jj = t >> 4;
-        const int j = jbase + jj, k = c0 + cc;
-        int tap;
-        if (p.tapmode == TM_ID) {
-          tap = s;
-        } else if (p.tapmode == TM_FLIP) {
-          tap = C::NS - 1 - s;
-        } else {
-          const int sy = s / 3, sx = s - sy * 3;
-          const int ky = (sy == 1) ? py : ((sy == 0 && py == 0) ? 2 : -1);
-          const int kx = (sx == 1) ? px : ((sx == 0 && px == 0) ? 2 : -1);
-          tap = (ky < 0 || kx < 0) ? -1 : ky * 3 + kx;
-        }
-        float v = 0.f;
-        if (j < p.J && k < p.K && tap >= 0) v = p.w[(long long)j * p.w_js + (long long)k * p.w_ks + tap];
-        wl[(((cc >> 2) * C::NS + s) * NT + (jj >> 4)) * 64 + (cc & 3) * 16 + (jj & 15)] = v;
+        int lidx;
+        (void)weight_index(e, c0, lidx);
+        wl[lidx] = rwt[i];
       }
     }
+  };
+
+  issue(0);
+  for (int ch = 0; ch < nchunk; ++ch) {
+    if (ch > 0) __syncthreads();  // every wave is done reading the previous chunk
+    commit(ch);
     __syncthreads();
+    if (ch + 1 < nchunk) issue(ch + 1);
     // ---- MFMA (channels past K are zero-filled in LDS, so all four 4-channel groups always run) ----
     if constexpr (CLS) {  // ConvTranspose2d output parity class: only the taps with matching parity exist
       switch (cls) {
@@ -470,7 +504,7 @@ struct WgCfg {
 // Block: MT M-tiles x 4 N-tiles (one per wave); loops over `items_per_chunk` (sample, tile) items,
 // accumulating in registers, then writes one partial slab; a reduce kernel sums the slabs in order.
 template <int KS, int MT, int PRO, bool SHIFT_A, int TH, int TW>
-__global__ __launch_bounds__(256) void wgrad_k(const WgradParams p) {
+__global__ __launch_bounds__(256, 2) void wgrad_k(const WgradParams p) {
   using C = WgCfg<KS, MT, PRO, SHIFT_A, TH, TW>;
   extern __shared__ __align__(16) float smem[];
   float* vl = smem;
@@ -483,26 +517,16 @@ __global__ __launch_bounds__(256) void wgrad_k(const WgradParams p) {
   const int ubase = SHIFT_A ? nbase : mbase;
   const int vbase = SHIFT_A ? mbase : nbase;
 
-  // V staging positions relative to the tile origin
-  int vr[C::NPOS], vc[C::NPOS];
-#pragma unroll
-  for (int i = 0; i < C::NPOS; ++i) {
-    const int e = tid + 256 * i;
-    vr[i] = -100000;
-    vc[i] = 0;
-    if (e < C::POS) {
-      if constexpr (C::S2D) {
-        const int pl = e / C::PLANE, rem = e - pl * C::PLANE;
-        const int r = rem / C::PITCH, col = rem - r * C::PITCH;
-        vr[i] = 2 * r + (pl >> 1);
-        vc[i] = 2 * col + (pl & 1);
-      } else {
-        const int r = e / C::PITCH, col = e - r * C::PITCH;
-        vr[i] = r - C::HALO / 2;
-        vc[i] = col - C::HALO / 2;
-      }
-    }
-  }
+  // Staging map: a thread owns one tile position (and, for images of <= 128 positions, one of two channels
+  // staged per pass); a pass moves 256 values.  Per-thread state is one relative offset per sub-pass.
+  constexpr int UPIX = TH * TW;                       // 128
+  constexpr int UG = 256 / UPIX;                      // channels per U pass (2)
+  constexpr int NUP = C::UCH / UG;                    // U passes
+  constexpr int VG = (C::POS <= 128) ? 2 : 1;         // channels per V pass
+  constexpr int VSUB = (VG == 2) ? 1 : cdiv(C::POS, 256);  // sub-passes per channel
+  constexpr int NVP = (C::VCH / VG) * VSUB;           // V loads per thread
+  static_assert(UPIX == 128 && C::UCH % UG == 0 && C::VCH % VG == 0, "staging map assumes 128-pixel tiles");
+  float ru[NUP], rv[NVP];
 
   f32x4 acc[MT][C::NS];
 #pragma unroll
@@ -516,86 +540,124 @@ __global__ __launch_bounds__(256) void wgrad_k(const WgradParams p) {
   long long it1 = it0 + p.items_per_chunk;
   if (it1 > total) it1 = total;
 
-  for (long long it = it0; it < it1; ++it) {
+  // U: thread -> (sub-channel, pixel)
+  const int u_sub = tid / UPIX, u_q = tid - u_sub * UPIX;
+  const int u_ty = u_q / TW, u_tx = u_q - u_ty * TW;
+  // V: thread -> (sub-channel, VSUB positions): source row/col relative to the tile origin
+  const int v_sub = (VG == 2) ? tid / 128 : 0;
+  int v_dy[VSUB], v_dx[VSUB], v_pos[VSUB];
+#pragma unroll
+  for (int k = 0; k < VSUB; ++k) {
+    const int pos = (VG == 2) ? (tid & 127) : (tid + 256 * k);
+    v_pos[k] = (pos < C::POS) ? pos : -1;
+    if constexpr (C::S2D) {
+      const int pl = pos / C::PLANE, rem = pos - pl * C::PLANE;
+      const int r = rem / C::PITCH, col = rem - r * C::PITCH;
+      v_dy[k] = 2 * r + (pl >> 1);
+      v_dx[k] = 2 * col + (pl & 1);
+    } else {
+      const int r = pos / C::PITCH, col = pos - r * C::PITCH;
+      v_dy[k] = r - C::HALO / 2;
+      v_dx[k] = col - C::HALO / 2;
+    }
+  }
+
+  // Register-staged pipeline (see igemm_k): loads of item it+1 fly while item it is in the MFMA phase.
+  auto issue = [&](long long it) {
     const int n = (int)(it / tiles);
     const int t = (int)(it - (long long)n * tiles);
     const int tile_y = t / p.tiles_x, tile_x = t - tile_y * p.tiles_x;
     const int gy0 = tile_y * TH, gx0 = tile_x * TW;
-    __syncthreads();
-    // ---- U tile (raw, no halo) ----
+    // Unconditional loads from clamped (always valid) addresses + a select: straight-line code, no per-load
+    // branch.  Address = uniform channel base (SGPR pair, clamped) + ONE 32-bit per-thread offset.
     {
+      const int gy = gy0 + u_ty, gx = gx0 + u_tx;
+      const bool ok = gy < p.GH && gx < p.GW;
+      const int usafe = min(u_sub, p.Uc - 1);
+      const int uoff = usafe * p.u_cs + (ok ? gy * p.GW + gx : 0);
       const float* un = p.u + (long long)n * p.u_ns;
-      for (int e = tid; e < C::UCH * TH * TW; e += 256) {
-        const int cc = e / (TH * TW), q = e - cc * (TH * TW);
-        const int ty = q / TW, tx = q - ty * TW;
-        const int gy = gy0 + ty, gx = gx0 + tx, c = ubase + cc;
-        float v = 0.f;
-        if (c < p.Uc && gy < p.GH && gx < p.GW) v = un[(long long)c * p.u_cs + (long long)gy * p.GW + gx];
-        ul[cc * C::UST + q] = v;
-      }
-    }
-    // ---- V tile (shifted operand) ----
-    {
-      const float* vn = p.v + (long long)n * p.v_ns;
-      const int oy = C::S2D ? 2 * gy0 : gy0, ox = C::S2D ? 2 * gx0 : gx0;
-#pragma unroll 4
-      for (int cc = 0; cc < C::VCH; ++cc) {
-        const int c = vbase + cc;
-        const bool cv = c < p.Vc;
-        const float* src = vn + (long long)c * p.v_cs;
-        float a = 1.f, b = 0.f;
-        if constexpr (PRO == PRO_BNRELU) {
-          if (cv) {
-            a = p.pa[c];
-            b = p.pb[c];
-          }
-        }
+      const int cumax = max(p.Uc - UG, 0);
 #pragma unroll
-        for (int i = 0; i < C::NPOS; ++i) {
-          const int e = tid + 256 * i;
-          if (e < C::POS) {
-            const int iy = oy + vr[i], ix = ox + vc[i];
-            float v = 0.f;
-            if (cv && iy >= 0 && iy < p.Hv && ix >= 0 && ix < p.Wv) {
-              v = src[(long long)iy * p.Wv + ix];
-              if constexpr (PRO == PRO_BNRELU) v = fmaxf(fmaf(a, v, b), 0.f);
-            }
-            vl[cc * C::VST + e] = v;
-          }
-        }
+      for (int i = 0; i < NUP; ++i) {
+        const float* chan = un + (long long)min(ubase + i * UG, cumax) * p.u_cs;
+        const float v = chan[uoff];
+        ru[i] = (ok && ubase + i * UG + u_sub < p.Uc) ? v : 0.f;
       }
     }
+    const int oy = C::S2D ? 2 * gy0 : gy0, ox = C::S2D ? 2 * gx0 : gx0;
+    const float* vn = p.v + (long long)n * p.v_ns;
+    const int vsafe = min(v_sub, p.Vc - 1);
+    const int cvmax = max(p.Vc - VG, 0);
+#pragma unroll
+    for (int k = 0; k < VSUB; ++k) {
+      const int iy = oy + v_dy[k], ix = ox + v_dx[k];
+      const bool ok = v_pos[k] >= 0 && iy >= 0 && iy < p.Hv && ix >= 0 && ix < p.Wv;
+      const int voff = vsafe * p.v_cs + (ok ? iy * p.Wv + ix : 0);
+#pragma unroll
+      for (int i = 0; i < C::VCH / VG; ++i) {
+        const int cu = min(vbase + i * VG, cvmax);  // uniform
+        const float* chan = vn + (long long)cu * p.v_cs;
+        float v = chan[voff];
+        if constexpr (PRO == PRO_BNRELU) {
+          const float* pa = p.pa + cu;
+          const float* pb = p.pb + cu;
+          v = fmaxf(fmaf(pa[vsafe], v, pb[vsafe]), 0.f);
+        }
+        rv[i * VSUB + k] = (ok && vbase + i * VG + v_sub < p.Vc) ? v : 0.f;
+      }
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < NUP; ++i) ul[(i * UG + u_sub) * C::UST + u_q] = ru[i];
+#pragma unroll
+    for (int k = 0; k < VSUB; ++k) {
+      if (v_pos[k] >= 0) {
+#pragma unroll
+        for (int i = 0; i < C::VCH / VG; ++i) vl[(i * VG + v_sub) * C::VST + v_pos[k]] = rv[i * VSUB + k];
+      }
+    }
+  };
+
+  if (it0 < it1) issue(it0);
+  for (long long it = it0; it < it1; ++it) {
+    __syncthreads();  // every wave is done reading the previous item
+    commit();
     __syncthreads();
+    if (it + 1 < it1) issue(it + 1);
     // ---- MFMA over the tile's pixels, 4 consecutive x per k-step; straight-line, constexpr LDS offsets ----
     {
       const float* ubase = ul + lj * C::UST + lk;
       const float* vbase = vl + lj * C::VST + lk;
       const float* uw = ubase + (SHIFT_A ? wave * 16 * C::UST : 0);
       const float* vw = vbase + (SHIFT_A ? 0 : wave * 16 * C::VST);
+      constexpr int KPR = TW / 4;  // k-steps per tile row
+#pragma unroll 1
+      for (int ty = 0; ty < TH; ++ty) {
+        const float* ur = uw + ty * TW;
+        const float* vr = vw + ty * C::PITCH;
+#pragma unroll 2
+        for (int kx = 0; kx < KPR; ++kx) {
+          const int tx0 = kx * 4;
+          if constexpr (!SHIFT_A) {
+            float a[MT];
 #pragma unroll
-      for (int ks = 0; ks < TH * TW / 4; ++ks) {
-        constexpr int KPR = TW / 4;
-        const int ty = ks / KPR, tx0 = (ks % KPR) * 4;
-        const int upix = ty * TW + tx0;
-        const int vpix = ty * C::PITCH + tx0;
-        if constexpr (!SHIFT_A) {
-          float a[MT];
+            for (int mt = 0; mt < MT; ++mt) a[mt] = ur[mt * 16 * C::UST + tx0];
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) a[mt] = uw[mt * 16 * C::UST + upix];
+            for (int s = 0; s < C::NS; ++s) {
+              const float b = vr[C::slot_off(s) + tx0];
 #pragma unroll
-          for (int s = 0; s < C::NS; ++s) {
-            const float b = vw[C::slot_off(s) + vpix];
+              for (int mt = 0; mt < MT; ++mt) acc[mt][s] = mfma16(a[mt], b, acc[mt][s]);
+            }
+          } else {
+            const float b = ur[tx0];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt][s] = mfma16(a[mt], b, acc[mt][s]);
-          }
-        } else {
-          const float b = uw[upix];
+            for (int s = 0; s < C::NS; ++s) {
 #pragma unroll
-          for (int s = 0; s < C::NS; ++s) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-              const float a = vw[mt * 16 * C::VST + C::slot_off(s) + vpix];
-              acc[mt][s] = mfma16(a, b, acc[mt][s]);
+              for (int mt = 0; mt < MT; ++mt) {
+                const float a = vr[mt * 16 * C::VST + C::slot_off(s) + tx0];
+                acc[mt][s] = mfma16(a, b, acc[mt][s]);
+              }
             }
           }
         }
