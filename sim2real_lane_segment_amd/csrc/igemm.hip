@@ -131,77 +131,118 @@ __global__ __launch_bounds__(256, (NT == 1 ? 4 : 2)) void igemm_k(const IgemmPar
 
   // Register-staged software pipeline: the global loads of chunk ch+1 are issued BEFORE the MFMA phase of
   // chunk ch and committed (activation applied, written to LDS) after it, so HBM/L2 latency hides under MFMA.
+  // Loads are unconditional from clamped, always-valid addresses (uniform channel base in SGPRs + one 32-bit
+  // per-thread offset); validity is applied as a select at commit time -> no exec-mask branches per load.
   float rin[16][C::NPOS];
   float rwt[C::NWE];
-  auto weight_index = [&](int e, int c0, int& lidx) -> long long {
-    const int s = e % C::NS, t = e / C::NS;
-    const int cc = t & 15, jj = t >> 4;
-    const int j = jbase + jj, k = c0 + cc;
-    int tap;
-    if (p.tapmode == TM_ID) {
-      tap = s;
-    } else if (p.tapmode == TM_FLIP) {
-      tap = C::NS - 1 - s;
-    } else {
-      const int sy = s / 3, sx = s - sy * 3;
-      const int ky = (sy == 1) ? py : ((sy == 0 && py == 0) ? 2 : -1);
-      const int kx = (sx == 1) ? px : ((sx == 0 && px == 0) ? 2 : -1);
-      tap = (ky < 0 || kx < 0) ? -1 : ky * 3 + kx;
+  int gsafe[C::NPOS];
+#pragma unroll
+  for (int i = 0; i < C::NPOS; ++i) gsafe[i] = goff[i] >= 0 ? goff[i] : 0;
+  // weight slab element handled by this thread in pass i: global offset relative to (jbase, c0), LDS slot,
+  // input-channel-in-chunk and validity, packed:  wmeta = lds_index | cc << 20 | valid << 28
+  auto wdecode = [&](int e, int& go, int& meta) {
+    go = 0;
+    meta = -1;
+    if (e < C::WE) {
+      const int s = e % C::NS, t = e / C::NS;
+      const int cc = t & 15, jj = t >> 4;
+      int tap;
+      if (p.tapmode == TM_ID) {
+        tap = s;
+      } else if (p.tapmode == TM_FLIP) {
+        tap = C::NS - 1 - s;
+      } else {
+        const int sy = s / 3, sx = s - sy * 3;
+        const int ky = (sy == 1) ? py : ((sy == 0 && py == 0) ? 2 : -1);
+        const int kx = (sx == 1) ? px : ((sx == 0 && px == 0) ? 2 : -1);
+        tap = (ky < 0 || kx < 0) ? -1 : ky * 3 + kx;
+      }
+      const bool valid = (jbase + jj < p.J) && tap >= 0;
+      const int jrel = min(jbase + jj, p.J - 1) - jbase;
+      go = (int)(jrel * p.w_js + cc * p.w_ks) + max(tap, 0);
+      const int lidx = (((cc >> 2) * C::NS + s) * NT + (jj >> 4)) * 64 + (cc & 3) * 16 + (jj & 15);
+      meta = lidx | (cc << 20) | ((valid ? 1 : 0) << 28);
     }
-    lidx = (((cc >> 2) * C::NS + s) * NT + (jj >> 4)) * 64 + (cc & 3) * 16 + (jj & 15);
-    return (j < p.J && k < p.K && tap >= 0) ? ((long long)j * p.w_js + (long long)k * p.w_ks + tap) : -1;
   };
+  // small slabs: keep the decode in registers across chunks; large slabs (few chunks): recompute per chunk
+  constexpr bool WHOIST = C::NWE <= 12;
+  constexpr int NWH = WHOIST ? C::NWE : 1;
+  int wgo_h[NWH], wmeta_h[NWH];
+  if constexpr (WHOIST) {
+#pragma unroll
+    for (int i = 0; i < C::NWE; ++i) wdecode(tid + 256 * i, wgo_h[i], wmeta_h[i]);
+  }
+  auto wget = [&](int i, int tid_o, int& go, int& meta) {
+    if constexpr (WHOIST) {
+      go = wgo_h[i];
+      meta = wmeta_h[i];
+    } else {
+      wdecode(tid_o + 256 * i, go, meta);
+    }
+  };
+  const float* wj = p.w + (long long)jbase * p.w_js;
   auto issue = [&](int ch) {
     const int c0 = ch * 16;
+    const int kmax = p.K - 1;
 #pragma unroll
     for (int cc = 0; cc < 16; ++cc) {
-      const int c = c0 + cc;
-      const bool cv = c < p.K;
-      const float* src = in_n + (long long)c * p.in_cs;
+      const float* src = in_n + (long long)min(c0 + cc, kmax) * p.in_cs;  // uniform, clamped
 #pragma unroll
-      for (int i = 0; i < C::NPOS; ++i) rin[cc][i] = (cv && goff[i] >= 0) ? src[goff[i]] : 0.f;
+      for (int i = 0; i < C::NPOS; ++i) rin[cc][i] = src[gsafe[i]];
     }
+    const float* wb = wj + (long long)c0 * p.w_ks;
     int tid_o = tid;
-    asm volatile("" : "+v"(tid_o));  // opaque: recompute the cheap decode per chunk instead of hoisting it
+    if constexpr (!WHOIST) asm volatile("" : "+v"(tid_o));  // opaque: do not hoist the large decode
+    if (c0 + 16 <= p.K) {
 #pragma unroll
-    for (int i = 0; i < C::NWE; ++i) {
-      const int e = tid_o + 256 * i;
-      int lidx;
-      const long long gi = (e < C::WE) ? weight_index(e, c0, lidx) : -1;
-      rwt[i] = (gi >= 0) ? p.w[gi] : 0.f;
+      for (int i = 0; i < C::NWE; ++i) {
+        int go, meta;
+        wget(i, tid_o, go, meta);
+        rwt[i] = wb[go];
+      }
+    } else {  // partial last chunk: clamp the input-channel index
+      const int krem = p.K - 1 - c0;
+#pragma unroll
+      for (int i = 0; i < C::NWE; ++i) {
+        int go, meta;
+        wget(i, tid_o, go, meta);
+        const int cc = (meta >> 20) & 15;
+        rwt[i] = wb[go - (cc - min(cc, krem)) * (int)p.w_ks];
+      }
     }
   };
   auto commit = [&](int ch) {
     const int c0 = ch * 16;
+    const int kmax = p.K - 1;
 #pragma unroll
     for (int cc = 0; cc < 16; ++cc) {
       const int c = c0 + cc;
-      const bool cv = c < p.K;
+      const bool cv = c <= kmax;
       float a = 1.f, b = 0.f;
       if constexpr (PRO == PRO_BNRELU) {
-        if (cv) {
-          a = p.pa[c];
-          b = p.pb[c];
-        }
+        a = p.pa[min(c, kmax)];
+        b = p.pb[min(c, kmax)];
       }
 #pragma unroll
       for (int i = 0; i < C::NPOS; ++i) {
         if (loff[i] >= 0) {
           float v = rin[cc][i];
-          if constexpr (PRO == PRO_BNRELU) v = (cv && goff[i] >= 0) ? fmaxf(fmaf(a, v, b), 0.f) : 0.f;
-          zl[cc * C::CHS + loff[i]] = v;
+          if constexpr (PRO == PRO_BNRELU) v = fmaxf(fmaf(a, v, b), 0.f);
+          zl[cc * C::CHS + loff[i]] = (cv && goff[i] >= 0) ? v : 0.f;
         }
       }
     }
+    const int krem = p.K - c0;  // channels of this chunk that exist
     int tid_o = tid;
-    asm volatile("" : "+v"(tid_o));
+    if constexpr (!WHOIST) asm volatile("" : "+v"(tid_o));
 #pragma unroll
     for (int i = 0; i < C::NWE; ++i) {
-      const int e = tid_o + 256 * i;
-      if (e < C::WE) {
-        int lidx;
-        (void)weight_index(e, c0, lidx);
-        wl[lidx] = rwt[i];
+      int go, meta;
+      wget(i, tid_o, go, meta);
+      if (meta >= 0) {
+        const int cc = (meta >> 20) & 15;
+        const bool valid = ((meta >> 28) & 1) && cc < krem;
+        wl[meta & 0xFFFFF] = valid ? rwt[i] : 0.f;
       }
     }
   };
