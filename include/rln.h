@@ -152,6 +152,9 @@ int rln_profile_num_classes(void);
 const char* rln_profile_class_name(int cls);
 int rln_profile_read(rln_ctx* ctx, double* ms, double* flops, double* bytes, int64_t* launches);
 
+/* diagnostic only: in-kernel cycle stamps of the dense forward kernel (enabled by env RLN_DBG=16) */
+int rln_debug_read_stamps(unsigned long long* out8);
+
 /* rln_op_classifier: FCDenseNetClassifier.forward on caller-provided weights (tiramisu.py:120-125):
  * out[n,k,p] = softmax_k((sum_c w[k,c]*feat[n,c,p] + b[k]) / T). */
 int rln_op_classifier(const float* feat, int n, int c, int hw, const float* w, const float* b, int ncls, float T,

@@ -63,6 +63,7 @@ _PROTOS = {
     "rln_profile_class_name": (c_char_p, [c_int]),
     "rln_profile_read": (c_int, [c_void_p, POINTER(ctypes.c_double), POINTER(ctypes.c_double),
                                  POINTER(ctypes.c_double), POINTER(c_int64)]),
+    "rln_debug_read_stamps": (c_int, [POINTER(ctypes.c_uint64)]),
     "rln_op_classifier": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_int,
                                   c_void_p]),
 }

@@ -47,7 +47,12 @@ struct IgemmParams {
   const float* einvstd;
   const float* egamma;
   int acc_lo, acc_hi;  // channels in [acc_lo,acc_hi) accumulate into out, others overwrite
+  int ksplit;          // >1: input-channel chunks split over blockIdx.y; raw partial sums go to out + split*split_stride
+  long long split_stride;
+  int dbg;             // timing ablations only (RLN_DBG): 1 skip global loads, 2 skip LDS commit, 4 skip MFMA, 16 stamps
+  unsigned long long* dbg_out;  // [8] phase cycle sums (diagnostic build path only)
 };
+unsigned long long* igemm_debug_buffer();  // device buffer of 8 counters (allocated on first use)
 
 // which compiled variant
 enum IgemmKind {
@@ -64,10 +69,14 @@ enum IgemmKind {
 int igemm_launch(IgemmKind kind, int tile, const IgemmParams& p, int N, hipStream_t stream);
 void igemm_tile_dims(IgemmKind kind, int tile, int* th, int* tw);
 int igemm_pick_tile(int gh, int gw);
+int igemm_pick_strip_tile(int gw);  // 2: 4x160, 3: 8x80, -1: none (dense forward only)
 // number of stat-partial blocks a launch produces
 inline long long igemm_stat_blocks(const IgemmParams& p, int N) {
   return (long long)p.ncls * p.tiles_x * p.tiles_y * N;
 }
+
+// dense-layer data gradient in looped form (K <= 16): same parameters as IG_DGRAD3, 4 stat-partial rows per block
+int dgrad_loop_launch(int tile, const IgemmParams& p, int N, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // weight gradient family: dW[m][n][tap] = sum_pixels U[m][p] * V[n][p + tap]  (or roles swapped)

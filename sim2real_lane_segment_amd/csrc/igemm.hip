@@ -12,19 +12,27 @@
 // so that the B-operand read is lane-linear.
 #include "igemm.h"
 
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
 namespace rln {
 
-template <int KS, int NT, int PRO, int EPI, int TH, int TW>
+// V4: the tile image is 16-byte aligned in x (it starts 4 columns left of the tile and is TW+8 wide for 3x3), so
+// global loads are dwordx4 and LDS commits are ds_write_b128 (needs W % 4 == 0 and 16-byte aligned rows).
+template <int KS, int NT, int PRO, int EPI, int TH, int TW, bool V4 = false>
 struct IgCfg {
   static constexpr int CK = 16;
   static constexpr bool S2D = (PRO == PRO_S2D);
   static constexpr int HALO = KS - 1;
-  static constexpr int PITCH = S2D ? (TW + 1) : (TW + HALO);
+  static constexpr int XPAD = (V4 && KS == 3) ? 4 : HALO / 2;  // columns staged left of the tile
+  static constexpr int PITCH = S2D ? (TW + 1) : (V4 ? (TW + (KS == 3 ? 8 : 0)) : (TW + HALO));
   static constexpr int ROWS = S2D ? (TH + 1) : (TH + HALO);
   static constexpr int PLANE = PITCH * ROWS;
   static constexpr int POS = PLANE * (S2D ? 4 : 1);
   static constexpr int CHS = round_mod32(POS, 16);
   static constexpr int NPOS = cdiv(POS, 256);
+  static constexpr int NQ = cdiv(CK * POS / 4, 256);  // V4: float4 loads per thread and chunk
   static constexpr int NS = KS * KS;
   static constexpr int IN_FLOATS = CK * CHS;
   static constexpr int W_FLOATS = (CK / 4) * NS * NT * 64;
@@ -38,7 +46,7 @@ struct IgCfg {
   static constexpr int MPW = TH * TW / 64;
   __host__ __device__ static constexpr int slot_off(int s) {
     return S2D ? ((((s / 3) & 1) * 2 + ((s % 3) & 1)) * PLANE + ((s / 3) >> 1) * PITCH + ((s % 3) >> 1))
-               : ((s / KS) * PITCH + (s % KS));
+               : ((s / KS) * PITCH + (s % KS) + (XPAD - HALO / 2));
   }
 };
 
@@ -68,9 +76,10 @@ __device__ __forceinline__ void igemm_compute(const float* __restrict__ zbase, c
   }
 }
 
-template <int KS, int NT, int PRO, int EPI, int TH, int TW, bool CLS>
-__global__ __launch_bounds__(256, (NT == 1 ? 4 : 2)) void igemm_k(const IgemmParams p) {
-  using C = IgCfg<KS, NT, PRO, EPI, TH, TW>;
+template <int KS, int NT, int PRO, int EPI, int TH, int TW, bool CLS, bool V4>
+__global__ __launch_bounds__(256, ((NT == 1 && TH * TW <= 256) ? 4 : 2)) void igemm_k(const IgemmParams p) {
+  using C = IgCfg<KS, NT, PRO, EPI, TH, TW, V4>;
+  static_assert(!V4 || (PRO != PRO_S2D && C::CHS % 4 == 0 && C::PITCH % 4 == 0), "V4 needs 16-byte aligned LDS rows");
   constexpr int MPW = C::MPW;
   static_assert(TW % 16 == 0 && (TH * TW) % 64 == 0, "tile must be whole M-tiles per wave");
   extern __shared__ __align__(16) float smem[];
@@ -90,17 +99,24 @@ __global__ __launch_bounds__(256, (NT == 1 ? 4 : 2)) void igemm_k(const IgemmPar
   const int tile_y = bx / p.tiles_x, tile_x = bx - tile_y * p.tiles_x;
   const int gy0 = tile_y * TH, gx0 = tile_x * TW;
   const int n = blockIdx.z;
-  const int jbase = blockIdx.y * (NT * 16);
+  int ky = 0, jy = blockIdx.y;
+  if (p.ksplit > 1) {
+    const int jgroups = (p.J + NT * 16 - 1) / (NT * 16);
+    ky = blockIdx.y / jgroups;
+    jy = blockIdx.y - ky * jgroups;
+  }
+  const int jbase = jy * (NT * 16);
   const int py = cls >> 1, px = cls & 1;
 
   // ---- per-thread staging positions (independent of the channel) ----
-  int goff[C::NPOS], loff[C::NPOS];
+  constexpr int NPOSX = V4 ? 1 : C::NPOS;
+  int goff[NPOSX], loff[NPOSX];
 #pragma unroll
-  for (int i = 0; i < C::NPOS; ++i) {
+  for (int i = 0; i < NPOSX; ++i) {
     const int e = tid + 256 * i;
     goff[i] = -1;
     loff[i] = -1;
-    if (e < C::POS) {
+    if (!V4 && e < C::POS) {
       int iy, ix;
       if constexpr (C::S2D) {
         const int pl = e / C::PLANE, rem = e - pl * C::PLANE;
@@ -133,11 +149,33 @@ __global__ __launch_bounds__(256, (NT == 1 ? 4 : 2)) void igemm_k(const IgemmPar
   // chunk ch and committed (activation applied, written to LDS) after it, so HBM/L2 latency hides under MFMA.
   // Loads are unconditional from clamped, always-valid addresses (uniform channel base in SGPRs + one 32-bit
   // per-thread offset); validity is applied as a select at commit time -> no exec-mask branches per load.
-  float rin[16][C::NPOS];
+  float rin[V4 ? 1 : 16][NPOSX];
   float rwt[C::NWE];
-  int gsafe[C::NPOS];
+  int gsafe[NPOSX];
 #pragma unroll
-  for (int i = 0; i < C::NPOS; ++i) gsafe[i] = goff[i] >= 0 ? goff[i] : 0;
+  for (int i = 0; i < NPOSX; ++i) gsafe[i] = goff[i] >= 0 ? goff[i] : 0;
+  // V4 staging map: thread -> NQ aligned quads (channel-in-chunk, row, 4 columns) of the chunk image
+  constexpr int NQX = V4 ? C::NQ : 1;
+  constexpr int QPR = C::PITCH / 4;                 // quads per image row
+  constexpr int QPC = C::ROWS * QPR;                // quads per channel
+  float4 rq[NQX];
+  int qg[NQX], qmeta[NQX];  // global offset (floats, incl. channel-in-chunk), lds float index | cc << 20 | valid << 28
+  if constexpr (V4) {
+#pragma unroll
+    for (int i = 0; i < NQX; ++i) {
+      const int e = tid + 256 * i;
+      qg[i] = 0;
+      qmeta[i] = -1;
+      if (e < 16 * QPC) {
+        const int cc = e / QPC, rem = e - cc * QPC;
+        const int r = rem / QPR, q = rem - r * QPR;
+        const int iy = gy0 - C::HALO / 2 + r, ix = gx0 - C::XPAD + 4 * q;
+        const bool ok = iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;  // W % 4 == 0: a quad is all-in or all-out
+        qg[i] = cc * p.in_cs + (ok ? iy * p.Win + ix : 0);
+        qmeta[i] = (cc * C::CHS + r * C::PITCH + 4 * q) | (cc << 20) | ((ok ? 1 : 0) << 28);
+      }
+    }
+  }
   // weight slab element handled by this thread in pass i: global offset relative to (jbase, c0), LDS slot,
   // input-channel-in-chunk and validity, packed:  wmeta = lds_index | cc << 20 | valid << 28
   auto wdecode = [&](int e, int& go, int& meta) {
@@ -184,11 +222,25 @@ __global__ __launch_bounds__(256, (NT == 1 ? 4 : 2)) void igemm_k(const IgemmPar
   auto issue = [&](int ch) {
     const int c0 = ch * 16;
     const int kmax = p.K - 1;
+    if constexpr (V4) {
+      const float* src = in_n + (long long)c0 * p.in_cs;  // uniform chunk base
+      const int krem = kmax - c0;
 #pragma unroll
-    for (int cc = 0; cc < 16; ++cc) {
-      const float* src = in_n + (long long)min(c0 + cc, kmax) * p.in_cs;  // uniform, clamped
+      for (int i = 0; i < NQX; ++i) {
+        int off = qg[i];
+        if (krem < 15 && qmeta[i] >= 0) {  // partial last chunk: clamp the channel (padding lanes keep offset 0)
+          const int cc = (qmeta[i] >> 20) & 15;
+          off -= (cc - min(cc, krem)) * p.in_cs;
+        }
+        rq[i] = *reinterpret_cast<const float4*>(src + off);
+      }
+    } else {
 #pragma unroll
-      for (int i = 0; i < C::NPOS; ++i) rin[cc][i] = src[gsafe[i]];
+      for (int cc = 0; cc < 16; ++cc) {
+        const float* src = in_n + (long long)min(c0 + cc, kmax) * p.in_cs;  // uniform, clamped
+#pragma unroll
+        for (int i = 0; i < NPOSX; ++i) rin[cc][i] = src[gsafe[i]];
+      }
     }
     const float* wb = wj + (long long)c0 * p.w_ks;
     int tid_o = tid;
@@ -206,7 +258,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? 4 : 2)) void igemm_k(const IgemmPar
       for (int i = 0; i < C::NWE; ++i) {
         int go, meta;
         wget(i, tid_o, go, meta);
-        const int cc = (meta >> 20) & 15;
+        const int cc = meta >= 0 ? ((meta >> 20) & 15) : 0;
         rwt[i] = wb[go - (cc - min(cc, krem)) * (int)p.w_ks];
       }
     }
@@ -214,21 +266,42 @@ __global__ __launch_bounds__(256, (NT == 1 ? 4 : 2)) void igemm_k(const IgemmPar
   auto commit = [&](int ch) {
     const int c0 = ch * 16;
     const int kmax = p.K - 1;
+    if constexpr (V4) {
 #pragma unroll
-    for (int cc = 0; cc < 16; ++cc) {
-      const int c = c0 + cc;
-      const bool cv = c <= kmax;
-      float a = 1.f, b = 0.f;
-      if constexpr (PRO == PRO_BNRELU) {
-        a = p.pa[min(c, kmax)];
-        b = p.pb[min(c, kmax)];
+      for (int i = 0; i < NQX; ++i) {
+        if (qmeta[i] >= 0) {
+          const int cc = (qmeta[i] >> 20) & 15;
+          const int c = c0 + cc;
+          const bool ok = ((qmeta[i] >> 28) & 1) && c <= kmax;
+          float4 v = rq[i];
+          if constexpr (PRO == PRO_BNRELU) {
+            const float a = p.pa[min(c, kmax)], b = p.pb[min(c, kmax)];
+            v.x = fmaxf(fmaf(a, v.x, b), 0.f);
+            v.y = fmaxf(fmaf(a, v.y, b), 0.f);
+            v.z = fmaxf(fmaf(a, v.z, b), 0.f);
+            v.w = fmaxf(fmaf(a, v.w, b), 0.f);
+          }
+          if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+          *reinterpret_cast<float4*>(zl + (qmeta[i] & 0xFFFFF)) = v;
+        }
       }
+    } else {
 #pragma unroll
-      for (int i = 0; i < C::NPOS; ++i) {
-        if (loff[i] >= 0) {
-          float v = rin[cc][i];
-          if constexpr (PRO == PRO_BNRELU) v = fmaxf(fmaf(a, v, b), 0.f);
-          zl[cc * C::CHS + loff[i]] = (cv && goff[i] >= 0) ? v : 0.f;
+      for (int cc = 0; cc < 16; ++cc) {
+        const int c = c0 + cc;
+        const bool cv = c <= kmax;
+        float a = 1.f, b = 0.f;
+        if constexpr (PRO == PRO_BNRELU) {
+          a = p.pa[min(c, kmax)];
+          b = p.pb[min(c, kmax)];
+        }
+#pragma unroll
+        for (int i = 0; i < NPOSX; ++i) {
+          if (loff[i] >= 0) {
+            float v = rin[cc][i];
+            if constexpr (PRO == PRO_BNRELU) v = fmaxf(fmaf(a, v, b), 0.f);
+            zl[cc * C::CHS + loff[i]] = (cv && goff[i] >= 0) ? v : 0.f;
+          }
         }
       }
     }
@@ -247,12 +320,46 @@ __global__ __launch_bounds__(256, (NT == 1 ? 4 : 2)) void igemm_k(const IgemmPar
     }
   };
 
-  issue(0);
-  for (int ch = 0; ch < nchunk; ++ch) {
-    if (ch > 0) __syncthreads();  // every wave is done reading the previous chunk
-    commit(ch);
+#ifdef RLN_DIAG
+  const bool stamps = (p.dbg & 16) != 0;
+#else
+  constexpr bool stamps = false;
+#endif
+  unsigned long long t_commit = 0, t_bar1 = 0, t_issue = 0, t_mfma = 0, t_bar2 = 0, t_last = 0;
+  auto stamp = [&](unsigned long long& acc) {
+    if (stamps) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): s_memtime returns through the scalar data path
+      acc += t - t_last;
+      t_last = t;
+    }
+  };
+#ifdef RLN_DIAG
+  const int dbg = p.dbg;
+#else
+  constexpr int dbg = 0;
+#endif
+  int ch_begin = 0, ch_end = nchunk;
+  if (p.ksplit > 1) {
+    const int per = (nchunk + p.ksplit - 1) / p.ksplit;
+    ch_begin = ky * per;
+    ch_end = min(nchunk, ch_begin + per);
+  }
+  if (!(dbg & 1) && ch_begin < ch_end) issue(ch_begin);
+  if (stamps) {
+    t_last = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+  }
+  for (int ch = ch_begin; ch < ch_end; ++ch) {
+    if (ch > ch_begin) __syncthreads();  // every wave is done reading the previous chunk
+    stamp(t_bar2);
+    if (!(dbg & 2)) commit(ch);
+    stamp(t_commit);
     __syncthreads();
-    if (ch + 1 < nchunk) issue(ch + 1);
+    stamp(t_bar1);
+    if (ch + 1 < ch_end && !(dbg & 1)) issue(ch + 1);
+    stamp(t_issue);
+    if (dbg & 4) continue;
     // ---- MFMA (channels past K are zero-filled in LDS, so all four 4-channel groups always run) ----
     if constexpr (CLS) {  // ConvTranspose2d output parity class: only the taps with matching parity exist
       switch (cls) {
@@ -264,6 +371,18 @@ __global__ __launch_bounds__(256, (NT == 1 ? 4 : 2)) void igemm_k(const IgemmPar
     } else {
       igemm_compute<C, NT, TW, (1u << C::NS) - 1u>(zbase, wlane, acc);
     }
+    if (stamps) {
+      asm volatile("" ::"v"(acc[0][0][0]));  // keep the MFMAs in front of the stamp
+      stamp(t_mfma);
+    }
+  }
+  if (stamps && lane == 0 && p.dbg_out != nullptr) {
+    atomicAdd(&p.dbg_out[0], t_commit);
+    atomicAdd(&p.dbg_out[1], t_bar1);
+    atomicAdd(&p.dbg_out[2], t_issue);
+    atomicAdd(&p.dbg_out[3], t_mfma);
+    atomicAdd(&p.dbg_out[4], t_bar2);
+    atomicAdd(&p.dbg_out[5], (unsigned long long)nchunk);
   }
 
   const long long blk_lin = (long long)n * gridDim.x + blockIdx.x;
@@ -303,7 +422,8 @@ __global__ __launch_bounds__(256, (NT == 1 ? 4 : 2)) void igemm_k(const IgemmPar
         if constexpr (EPI == EPI_STORE) {
           const int oy = gy * S_ + py;
           if (oy >= p.Hout) continue;
-          float* dst = p.out + (long long)n * p.out_ns + (long long)j * p.out_cs + (long long)oy * p.Wout;
+          float* dst = p.out + (long long)ky * p.split_stride + (long long)n * p.out_ns + (long long)j * p.out_cs +
+                       (long long)oy * p.Wout;
           const int ox0 = gx * S_ + px;
           float v[4];
 #pragma unroll
@@ -446,27 +566,73 @@ __global__ __launch_bounds__(256, (NT == 1 ? 4 : 2)) void igemm_k(const IgemmPar
   }
 }
 
-template <int KS, int NT, int PRO, int EPI, int TH, int TW, bool CLS = false>
-static int launch_t(const IgemmParams& p, int N, hipStream_t stream) {
-  using C = IgCfg<KS, NT, PRO, EPI, TH, TW>;
+template <int KS, int NT, int PRO, int EPI, int TH, int TW, bool CLS, bool V4>
+static int launch_v(const IgemmParams& p, int N, hipStream_t stream) {
+  using C = IgCfg<KS, NT, PRO, EPI, TH, TW, V4>;
   static bool attr_done = false;
-  auto kern = igemm_k<KS, NT, PRO, EPI, TH, TW, CLS>;
+  auto kern = igemm_k<KS, NT, PRO, EPI, TH, TW, CLS, V4>;
   if ((p.ncls > 1) != CLS) return -1;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               C::LDS_BYTES);
     (void)hipGetLastError();
     attr_done = true;
+    if (getenv("RLN_DEBUG_OCC")) {
+      int nb = -1;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 256, C::LDS_BYTES);
+      fprintf(stderr, "[rln] igemm_k<KS%d NT%d PRO%d EPI%d %dx%d CLS%d V4%d> lds %d B -> %d blocks/CU\n", KS, NT, PRO, EPI,
+              TH, TW, (int)CLS, (int)V4, C::LDS_BYTES, nb);
+    }
   }
-  dim3 grid((unsigned)(p.ncls * p.tiles_x * p.tiles_y), (unsigned)((p.J + NT * 16 - 1) / (NT * 16)), (unsigned)N);
+  dim3 grid((unsigned)(p.ncls * p.tiles_x * p.tiles_y),
+            (unsigned)(((p.J + NT * 16 - 1) / (NT * 16)) * (p.ksplit > 1 ? p.ksplit : 1)), (unsigned)N);
+  static const int dbg = getenv("RLN_DBG") ? atoi(getenv("RLN_DBG")) : 0;
+  if (dbg) {
+    IgemmParams q = p;
+    q.dbg = dbg;
+    // stamps only for the kernel class selected by RLN_DBG_KS / RLN_DBG_NT (default: dense forward KS3 NT1 BNRELU)
+    q.dbg_out = ((dbg & 16) && KS == 3 && NT == 1 && PRO == PRO_BNRELU) ? igemm_debug_buffer() : nullptr;
+    if (!q.dbg_out) q.dbg &= ~16;
+    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, stream, q);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, stream, p);
   return (int)hipGetLastError();
+}
+
+// picks the 16-byte staging variant when the K-side operand allows it
+template <int KS, int NT, int PRO, int EPI, int TH, int TW, bool CLS = false>
+static int launch_t(const IgemmParams& p, int N, hipStream_t stream) {
+  if constexpr (PRO != PRO_S2D) {
+    // measured: on the small tiles the 16-byte staging path is not faster than the scalar one (the tile-with-halo
+    // pattern is bound by 128-byte line requests, not by instruction count); it is used by the strip tiles only.
+    static const bool want_v4 = getenv("RLN_V4_ALL") != nullptr;
+    const bool v4 = want_v4 && (p.Win % 4 == 0) && (p.in_cs % 4 == 0) && (p.in_ns % 4 == 0) &&
+                    ((((uintptr_t)p.in) & 15) == 0);
+    if (v4) return launch_v<KS, NT, PRO, EPI, TH, TW, CLS, true>(p, N, stream);
+  }
+  return launch_v<KS, NT, PRO, EPI, TH, TW, CLS, false>(p, N, stream);
+}
+
+unsigned long long* igemm_debug_buffer() {
+  static unsigned long long* buf = nullptr;
+  if (!buf) {
+    (void)hipMalloc(&buf, 8 * sizeof(unsigned long long));
+    (void)hipMemset(buf, 0, 8 * sizeof(unsigned long long));
+  }
+  return buf;
 }
 
 void igemm_tile_dims(IgemmKind kind, int tile, int* th, int* tw) {
   if (kind == IG_S2D3) {
     *th = 8;
     *tw = 16;
+  } else if (tile == 2) {  // full-width strips: no column halo, rows start on 128-byte lines
+    *th = 4;
+    *tw = 160;
+  } else if (tile == 3) {
+    *th = 8;
+    *tw = 80;
   } else if (tile == 0) {
     *th = 8;
     *tw = 32;
@@ -474,6 +640,12 @@ void igemm_tile_dims(IgemmKind kind, int tile, int* th, int* tw) {
     *th = 16;
     *tw = 16;
   }
+}
+
+// strip tiles need the 16-byte staging path: W % 4 == 0 and aligned planes (checked by the caller)
+int igemm_pick_strip_tile(int gw) {
+  if (getenv("RLN_NO_STRIP")) return -1;
+  return gw == 160 ? 2 : (gw == 80 ? 3 : -1);
 }
 
 int igemm_pick_tile(int gh, int gw) {
@@ -486,6 +658,8 @@ int igemm_pick_tile(int gh, int gw) {
 int igemm_launch(IgemmKind kind, int tile, const IgemmParams& p, int N, hipStream_t stream) {
   switch (kind) {
     case IG_CONV3_BN:
+      if (tile == 2) return launch_v<3, 1, PRO_BNRELU, EPI_STORE, 4, 160, false, true>(p, N, stream);
+      if (tile == 3) return launch_v<3, 1, PRO_BNRELU, EPI_STORE, 8, 80, false, true>(p, N, stream);
       return tile == 0 ? launch_t<3, 1, PRO_BNRELU, EPI_STORE, 8, 32>(p, N, stream)
                        : launch_t<3, 1, PRO_BNRELU, EPI_STORE, 16, 16>(p, N, stream);
     case IG_CONV3_RAW:
@@ -510,6 +684,233 @@ int igemm_launch(IgemmKind kind, int tile, const IgemmParams& p, int N, hipStrea
       return launch_t<3, 4, PRO_S2D, EPI_STORE, 8, 16>(p, N, stream);
   }
   return -1;
+}
+
+// =============================================================================================
+// dense-layer data gradient, looped form (K = growth <= 16 input channels = dY, J = Cin outputs)
+//
+// The 16-channel dY tile (+halo) is staged once; the block then walks the Cin output channels 16 at a time:
+// weight slab ct+1 is loaded while slab ct is in the MFMA phase (two LDS slab buffers, one barrier per step),
+// the epilogue operands (S for the ReLU mask / xhat, G for accumulation) are prefetched before the MFMA phase,
+// and the BatchNorm-backward partial sums leave the block per wave (4 partial rows per block).
+// =============================================================================================
+
+template <int TH, int TW>
+__global__ __launch_bounds__(256, 3) void dgrad_loop_k(const IgemmParams p) {
+  using C = IgCfg<3, 1, PRO_RAW, EPI_DGRAD, TH, TW>;
+  constexpr int MPW = C::MPW;
+  constexpr int NWE = C::NWE;  // 9 weight elements per thread and slab
+  extern __shared__ __align__(16) float smem[];
+  float* zl = smem;
+  float* wl0 = smem + C::IN_FLOATS;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, lj = lane & 15, lk = lane >> 4;
+  const int bx = blockIdx.x;
+  const int tile_y = bx / p.tiles_x, tile_x = bx - tile_y * p.tiles_x;
+  const int gy0 = tile_y * TH, gx0 = tile_x * TW;
+  const int n = blockIdx.z;
+
+  // ---- stage the dY tile once (clamped unconditional loads + select) ----
+  {
+    const float* in_n = p.in + (long long)n * p.in_ns;
+    const int kmax = p.K - 1;
+#pragma unroll
+    for (int i = 0; i < C::NPOS; ++i) {
+      const int e = tid + 256 * i;
+      if (e < C::POS) {
+        const int r = e / C::PITCH, col = e - r * C::PITCH;
+        const int iy = gy0 - 1 + r, ix = gx0 - 1 + col;
+        const bool ok = iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+        const int off = ok ? iy * p.Win + ix : 0;
+        float v[16];
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) v[cc] = in_n[(long long)min(cc, kmax) * p.in_cs + off];
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) zl[cc * C::CHS + e] = (ok && cc <= kmax) ? v[cc] : 0.f;
+      }
+    }
+  }
+  // ---- weight slab map: element (s, o = cc, c = jj) of a 16-channel output tile ----
+  int wgo[NWE], wmeta[NWE];
+#pragma unroll
+  for (int i = 0; i < NWE; ++i) {
+    const int e = tid + 256 * i;  // < 2304 always (9 * 256)
+    const int s = e % 9, t = e / 9;
+    const int cc = t & 15, jj = t >> 4;
+    wgo[i] = jj * (int)p.w_js + min(cc, p.K - 1) * (int)p.w_ks + (8 - s);
+    wmeta[i] = (((cc >> 2) * 9 + s) * 64 + (cc & 3) * 16 + jj) | (jj << 20) | ((cc < p.K ? 1 : 0) << 28);
+  }
+  float rwt[NWE];
+  const int nct = (p.J + 15) >> 4;
+  auto issue_w = [&](int ct) {
+    const float* wb = p.w + (long long)(ct * 16) * p.w_js;
+    if (ct * 16 + 16 <= p.J) {
+#pragma unroll
+      for (int i = 0; i < NWE; ++i) rwt[i] = wb[wgo[i]];
+    } else {
+      const int jrem = p.J - 1 - ct * 16;
+#pragma unroll
+      for (int i = 0; i < NWE; ++i) {
+        const int jj = (wmeta[i] >> 20) & 15;
+        rwt[i] = wb[wgo[i] - (jj - min(jj, jrem)) * (int)p.w_js];
+      }
+    }
+  };
+  auto commit_w = [&](int ct, float* wl) {
+    const int jrem = p.J - ct * 16;
+#pragma unroll
+    for (int i = 0; i < NWE; ++i) {
+      const int jj = (wmeta[i] >> 20) & 15;
+      const bool valid = ((wmeta[i] >> 28) & 1) && jj < jrem;
+      wl[wmeta[i] & 0xFFFFF] = valid ? rwt[i] : 0.f;
+    }
+  };
+
+  // ---- per-lane epilogue geometry: M-tile m covers 4 consecutive pixels of one row ----
+  int pixoff[MPW];
+  unsigned vmask = 0;  // 4 validity bits per M-tile
+#pragma unroll
+  for (int m = 0; m < MPW; ++m) {
+    const int q = (wave * MPW + m) * 16 + lk * 4;
+    const int ty = q / TW, tx = q - ty * TW;
+    const int gy = gy0 + ty, gx = gx0 + tx;
+    unsigned bits = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bits |= ((gy < p.GH && gx + r < p.GW) ? 1u : 0u) << r;
+    vmask |= bits << (4 * m);
+    pixoff[m] = (bits & 1u) ? gy * p.GW + gx : 0;  // clamped to a valid pixel when the whole group is outside
+  }
+  const bool vec = p.out_vec != 0;  // host: rows 16-byte aligned and W % 4 == 0 -> groups are all-in or all-out
+  const float* Sn = p.S + (long long)n * p.s_ns;
+  float* Gn = p.out + (long long)n * p.out_ns;
+  const float* zbase = zl + lk * C::CHS + ((wave * MPW * 16) / TW) * C::PITCH + lj;
+  const int nct16 = ((p.J + 15) >> 4) * 16;
+  float* red = wl0 + 2 * C::W_FLOATS;  // [4 waves][nct16][2]
+
+  // small grids: the output-channel tiles are split over blockIdx.y (disjoint outputs, no reduction)
+  const int ct_per = (nct + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int ct_begin = (int)blockIdx.y * ct_per;
+  const int ct_end = min(nct, ct_begin + ct_per);
+  if (ct_begin < ct_end) {
+    issue_w(ct_begin);
+    commit_w(ct_begin, wl0 + (ct_begin & 1) * C::W_FLOATS);
+  }
+  __syncthreads();
+  for (int ct = ct_begin; ct < ct_end; ++ct) {
+    float* wcur = wl0 + (ct & 1) * C::W_FLOATS;
+    float* wnext = wl0 + ((ct + 1) & 1) * C::W_FLOATS;
+    if (ct + 1 < ct_end) issue_w(ct + 1);
+    const int j = ct * 16 + lj;
+    const bool jv = j < p.J;
+    const int jc = min(j, p.J - 1);
+    const bool accum = (j >= p.acc_lo) && (j < p.acc_hi);
+    // prefetch epilogue operands (clamped addresses; invalid lanes/pixels are masked in the epilogue)
+    float sv[MPW][4], gv[MPW][4];
+    const float* Sc = Sn + (long long)jc * p.out_cs;
+    float* Gc = Gn + (long long)jc * p.out_cs;
+    if (vec) {
+#pragma unroll
+      for (int m = 0; m < MPW; ++m) {
+        const float4 t4 = *reinterpret_cast<const float4*>(Sc + pixoff[m]);
+        sv[m][0] = t4.x; sv[m][1] = t4.y; sv[m][2] = t4.z; sv[m][3] = t4.w;
+        const float4 g4 = *reinterpret_cast<const float4*>(Gc + pixoff[m]);
+        gv[m][0] = g4.x; gv[m][1] = g4.y; gv[m][2] = g4.z; gv[m][3] = g4.w;
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < MPW; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool ok = (vmask >> (4 * m + r)) & 1u;
+          sv[m][r] = Sc[pixoff[m] + (ok ? r : 0)];
+          gv[m][r] = Gc[pixoff[m] + (ok ? r : 0)];
+        }
+    }
+    const float ea = p.ea[jc], eb = p.eb[jc], emean = p.emean[jc], einv = p.einvstd[jc], egam = p.egamma[jc];
+
+    f32x4 acc[MPW][1];
+#pragma unroll
+    for (int m = 0; m < MPW; ++m) acc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    igemm_compute<C, 1, TW, 0x1FFu>(zbase, wcur + lane, acc);
+
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int m = 0; m < MPW; ++m) {
+      float ov[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool ok = jv && ((vmask >> (4 * m + r)) & 1u);
+        const float yv = fmaf(ea, sv[m][r], eb);
+        const float gyv = (ok && yv > 0.f) ? acc[m][0][r] : 0.f;
+        const float xh = (sv[m][r] - emean) * einv;
+        s1 += gyv;
+        s2 += gyv * xh;
+        ov[r] = fmaf(egam, gyv, accum ? gv[m][r] : 0.f);
+      }
+      if (vec) {
+        if (jv && ((vmask >> (4 * m)) & 1u))
+          *reinterpret_cast<float4*>(Gc + pixoff[m]) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (jv && ((vmask >> (4 * m + r)) & 1u)) Gc[pixoff[m] + r] = ov[r];
+      }
+    }
+    s1 = group4_sum(s1);
+    s2 = group4_sum(s2);
+    if (lk == 0) {  // per-wave slot in LDS; summed over the 4 waves after the loop
+      red[(wave * nct16 + j) * 2 + 0] = s1;
+      red[(wave * nct16 + j) * 2 + 1] = s2;
+    }
+    if (ct + 1 < ct_end) commit_w(ct + 1, wnext);
+    __syncthreads();
+  }
+  if (p.stat_partial != nullptr) {
+    const long long brow = (long long)n * gridDim.x + blockIdx.x;
+    for (int j = ct_begin * 16 + tid; j < min(p.J, ct_end * 16); j += 256) {
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        a1 += red[(w * nct16 + j) * 2 + 0];
+        a2 += red[(w * nct16 + j) * 2 + 1];
+      }
+      p.stat_partial[(brow * p.J + j) * 2 + 0] = a1;
+      p.stat_partial[(brow * p.J + j) * 2 + 1] = a2;
+    }
+  }
+}
+
+template <int TH, int TW>
+static int dgrad_loop_launch_t(const IgemmParams& p, int N, hipStream_t stream) {
+  using C = IgCfg<3, 1, PRO_RAW, EPI_DGRAD, TH, TW>;
+  const int LDS = (C::IN_FLOATS + 2 * C::W_FLOATS + 4 * (((p.J + 15) >> 4) * 16) * 2) * 4;
+  static bool attr_done = false;
+  auto kern = dgrad_loop_k<TH, TW>;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              96 * 1024);
+    (void)hipGetLastError();
+    attr_done = true;
+    if (getenv("RLN_DEBUG_OCC")) {
+      int nb = -1;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 256, LDS);
+      fprintf(stderr, "[rln] dgrad_loop_k<%dx%d> lds %d B -> %d blocks/CU\n", TH, TW, LDS, nb);
+    }
+  }
+  // aim for >= ~2 blocks per CU on small levels by splitting the output-channel loop
+  const long long base_blocks = (long long)p.tiles_x * p.tiles_y * N;
+  const int nct = (p.J + 15) / 16;
+  int split = 1;
+  if (base_blocks < 512) split = (int)std::min<long long>((512 + base_blocks - 1) / base_blocks, (long long)nct);
+  dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)split, (unsigned)N);
+  hipLaunchKernelGGL(kern, grid, dim3(256), LDS, stream, p);
+  return (int)hipGetLastError();
+}
+
+// K (= dY channels) must be <= 16.  One stat-partial row per block.
+int dgrad_loop_launch(int tile, const IgemmParams& p, int N, hipStream_t stream) {
+  if (p.K > 16 || p.ncls != 1) return -1;
+  return tile == 0 ? dgrad_loop_launch_t<8, 32>(p, N, stream) : dgrad_loop_launch_t<16, 16>(p, N, stream);
 }
 
 // =============================================================================================
@@ -731,6 +1132,12 @@ static int wlaunch_t(const WgradParams& p, hipStream_t stream) {
                               C::LDS_BYTES);
     (void)hipGetLastError();
     attr_done = true;
+    if (getenv("RLN_DEBUG_OCC")) {
+      int nb = -1;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 256, C::LDS_BYTES);
+      fprintf(stderr, "[rln] wgrad_k<KS%d MT%d PRO%d SA%d %dx%d> lds %d B -> %d blocks/CU\n", KS, MT, PRO, (int)SHIFT_A, TH,
+              TW, C::LDS_BYTES, nb);
+    }
   }
   const int Mc = SHIFT_A ? p.Vc : p.Uc;
   const int Nc = SHIFT_A ? p.Uc : p.Vc;

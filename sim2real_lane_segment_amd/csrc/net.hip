@@ -136,12 +136,21 @@ struct rln_ctx {
   float* masks = nullptr;
   float* stat_partial = nullptr;
   float* dY = nullptr;
+  float* fsplit = nullptr;  // forward split-K partial sums (small levels)
   float* wpartial = nullptr;
   float* bpartial = nullptr;
   float* glin = nullptr;
   unsigned char* pool_idx = nullptr;
   std::vector<int64_t> pool_off;  // per TD op index in ops
   LossScratch loss;
+  // backward concurrency: weight gradients run on a side stream next to the data-gradient chain
+  hipStream_t side = nullptr;
+  hipEvent_t ev_dy[2] = {nullptr, nullptr};  // dY[buf] written (main stream)
+  hipEvent_t ev_wg[2] = {nullptr, nullptr};  // last weight-gradient reading dY[buf] finished (side stream)
+  bool wg_pending[2] = {false, false};
+  float* dYbuf[2] = {nullptr, nullptr};
+  int dy_flip = 0;
+  bool use_side = false;
   // forward/backward hand-over state
   const float* last_x = nullptr;
   const int64_t* last_y = nullptr;
@@ -407,6 +416,14 @@ void level_dims(const rln_ctx* c, int h, int w, std::vector<int>& hs, std::vecto
   }
 }
 
+// forward split-K factor of a dense layer: small levels do not fill the chip with one block per tile
+int dense_fwd_split(long long blocks, int cin) {
+  if (blocks >= 256 || getenv("RLN_NO_SPLITK")) return 1;
+  const int nchunk = (cin + 15) / 16;
+  const long long want = (512 + blocks - 1) / blocks;
+  return (int)std::max<long long>(1, std::min<long long>(want, nchunk));
+}
+
 long long wgrad_chunks(long long total_items, int mgroups, int ngroups, int* ipc) {
   long long want = (1024 + (long long)mgroups * ngroups - 1) / ((long long)mgroups * ngroups);
   if (want < 1) want = 1;
@@ -433,7 +450,7 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
   float* ab = cv.take<float>(2 * c->n_ab);
   float* masks = cv.take<float>((size_t)n * c->drop_total);
   // scratch maxima
-  size_t stat_max = 0, dy_max = 0, wp_max = 0, bp_max = 0, pool_bytes = 0;
+  size_t stat_max = 0, dy_max = 0, wp_max = 0, bp_max = 0, pool_bytes = 0, fs_max = 0;
   std::vector<int64_t> pool_off(c->ops.size(), -1);
   for (size_t k = 0; k < c->ops.size(); ++k) {
     const Op& o = c->ops[k];
@@ -444,6 +461,13 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
       igemm_tile_dims(IG_CONV3_BN, tile, &th, &tw);
       const size_t blocks = (size_t)n * ((Hd + th - 1) / th) * ((Wd + tw - 1) / tw);
       stat_max = std::max(stat_max, blocks * o.cout * 2);
+      if (o.type == OP_DENSE) {
+        const int sp = dense_fwd_split((long long)blocks, o.cin);
+        if (sp > 1) {
+          fs_max = std::max(fs_max, (size_t)sp * n * o.cout * Hd * Wd);
+          stat_max = std::max(stat_max, (size_t)n * ((Hd * Wd + 255) / 256) * o.cout * 2);
+        }
+      }
       if (with_bwd) {
         stat_max = std::max(stat_max, blocks * o.cin * 2);
         dy_max = std::max(dy_max, (size_t)n * o.cout * Hd * Wd);
@@ -499,7 +523,9 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
   }
   float* stat_partial = cv.take<float>(stat_max);
   unsigned char* pool_idx = cv.take<unsigned char>(pool_bytes);
+  float* fsplit = cv.take<float>(fs_max);
   float* dY = with_bwd ? cv.take<float>(dy_max) : nullptr;
+  float* dY2 = with_bwd ? cv.take<float>(dy_max) : nullptr;
   float* wpartial = with_bwd ? cv.take<float>(wp_max) : nullptr;
   float* bpartial = with_bwd ? cv.take<float>(bp_max) : nullptr;
   float* glin = with_bwd ? cv.take<float>((size_t)n * c->cfg.n_classes * hw0) : nullptr;
@@ -524,7 +550,10 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
     c->stat_partial = stat_partial;
     c->pool_idx = pool_idx;
     c->pool_off = pool_off;
+    c->fsplit = fsplit;
     c->dY = dY;
+    c->dYbuf[0] = dY;
+    c->dYbuf[1] = dY2;
     c->wpartial = wpartial;
     c->bpartial = bpartial;
     c->glin = glin;
@@ -663,6 +692,9 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
     p.GW = (dl.W + 1) / 2;
   }
   tile = igemm_pick_tile(p.GH, p.GW);
+  if (kind == IG_CONV3_BN && igemm_pick_strip_tile(p.GW) >= 0 && aligned16(p.in) && (p.in_cs % 4) == 0 &&
+      (p.in_ns % 4) == 0)
+    tile = igemm_pick_strip_tile(p.GW);
   int th, tw;
   igemm_tile_dims(kind, tile, &th, &tw);
   p.tiles_y = (p.GH + th - 1) / th;
@@ -675,6 +707,26 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
     const int cls = o.type == OP_FIRST ? PC_FIRST_FWD : o.type == OP_DENSE ? PC_DENSE_FWD
                     : o.type == OP_TD  ? PC_TD_FWD : PC_TU_FWD;
     ProfScope ps(c, cls, flops, bytes, s);
+    const int sp = (o.type == OP_DENSE) ? dense_fwd_split(igemm_stat_blocks(p, N), o.cin) : 1;
+    if (sp > 1) {  // split-K: raw partial sums to scratch, then bias / dropout scale / statistics in the finish pass
+      IgemmParams q = p;
+      const int HW = dl.H * dl.W;
+      q.ksplit = sp;
+      q.split_stride = (long long)N * o.cout * HW;
+      q.out = c->fsplit;
+      q.out_ns = (long long)o.cout * HW;
+      q.out_cs = HW;
+      q.bias = nullptr;
+      q.nscale = nullptr;
+      q.stat_partial = nullptr;
+      q.out_vec = ((dl.W % 4) == 0 && aligned16(q.out)) ? 1 : 0;
+      RLN_TRY(igemm_launch(kind, tile, q, N, s));
+      long long nblk = 0;
+      RLN_TRY(splitk_finish(c->fsplit, sp, q.split_stride, N, o.cout, HW, p.bias, p.nscale, p.out, p.out_ns,
+                            p.stat_partial, &nblk, s));
+      if (training) RLN_TRY(finalize_stats(c, o.dst_level, o.out_off, o.cout, nblk, s));
+      return 0;
+    }
     RLN_TRY(igemm_launch(kind, tile, p, N, s));
   }
   if (training) RLN_TRY(finalize_stats(c, o.dst_level, o.out_off, o.cout, igemm_stat_blocks(p, N), s));
@@ -755,10 +807,45 @@ int run_wgrad(rln_ctx* c, WgradKind kind, WgradParams& w, int Mc, int Nc, int64_
   return 0;
 }
 
+// Picks the dY buffer for the next op and makes the main stream wait until the weight-gradient kernel that last
+// read it (side stream) has finished.
+int dy_acquire(rln_ctx* c, hipStream_t s) {
+  c->dy_flip ^= 1;
+  const int b = c->dy_flip;
+  c->dY = c->dYbuf[b];
+  if (c->use_side && c->wg_pending[b]) {
+    hipError_t e = hipStreamWaitEvent(s, c->ev_wg[b], 0);
+    if (e != hipSuccess) return fail((int)e, "hipStreamWaitEvent failed");
+    c->wg_pending[b] = false;
+  }
+  return 0;
+}
+// Called after dY[current] has been written on the main stream: returns the stream the weight gradient runs on.
+int wg_begin(rln_ctx* c, hipStream_t s, hipStream_t* ws) {
+  *ws = s;
+  if (!c->use_side) return 0;
+  const int b = c->dy_flip;
+  hipError_t e = hipEventRecord(c->ev_dy[b], s);
+  if (e == hipSuccess) e = hipStreamWaitEvent(c->side, c->ev_dy[b], 0);
+  if (e != hipSuccess) return fail((int)e, "side-stream hand-over failed");
+  *ws = c->side;
+  return 0;
+}
+int wg_end(rln_ctx* c) {
+  if (!c->use_side) return 0;
+  const int b = c->dy_flip;
+  hipError_t e = hipEventRecord(c->ev_wg[b], c->side);
+  if (e != hipSuccess) return fail((int)e, "hipEventRecord failed");
+  c->wg_pending[b] = true;
+  return 0;
+}
+
 int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
   const Op& o = c->ops[k];
   const int N = c->N;
   long long rows = 0;
+  hipStream_t ws = s;
+  RLN_TRY(dy_acquire(c, s));
   if (o.type == OP_DENSE || o.type == OP_FIRST) {
     const Level& lv = c->levels[o.dst_level];
     const size_t plane = (size_t)lv.H * lv.W;
@@ -808,10 +895,15 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
         const double flops = 2.0 * o.cin * o.cout * 9.0 * plane * N;
         const double bytes = 4.0 * N * plane * ((double)o.cout + 2.0 * o.cin + (double)(o.acc_hi - o.acc_lo));
         ProfScope ps(c, PC_DENSE_DGRAD, flops, bytes, s);
-        RLN_TRY(igemm_launch(IG_DGRAD3, tile, p, N, s));
+        if (o.cout <= 16) {
+          RLN_TRY(dgrad_loop_launch(tile, p, N, s));
+        } else {
+          RLN_TRY(igemm_launch(IG_DGRAD3, tile, p, N, s));
+        }
       }
       ProfScope psb(c, PC_BN, 0, 0, s);
-      RLN_TRY(bn_bwd_finalize(c->stat_partial, igemm_stat_blocks(p, N), o.cin, c->params + o.bn.gamma,
+      RLN_TRY(bn_bwd_finalize(c->stat_partial, igemm_stat_blocks(p, N), o.cin,
+                              c->params + o.bn.gamma,
                               c->grads + o.bn.gamma, c->grads + o.bn.beta, c->S1 + so, c->S2 + so, s));
     }
     WgradParams w;
@@ -829,17 +921,19 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
     w.wsize = (long long)o.cout * o.cin * 9;
     w.m_stride = (long long)o.cin * 9;
     w.n_stride = 9;
+    RLN_TRY(wg_begin(c, s, &ws));
     if (o.type == OP_DENSE) {
       w.v = lv.S + (size_t)o.in_off * plane;
       w.v_ns = (long long)lv.C * plane;
       w.pa = c->ab + o.bn.ab;
       w.pb = c->ab + c->n_ab + o.bn.ab;
-      RLN_TRY(run_wgrad(c, WG_DENSE3, w, o.cout, o.cin, o.conv.w, s));
+      RLN_TRY(run_wgrad(c, WG_DENSE3, w, o.cout, o.cin, o.conv.w, ws));
     } else {
       w.v = c->last_x;
       w.v_ns = (long long)o.cin * plane;
-      RLN_TRY(run_wgrad(c, WG_RAW3, w, o.cout, o.cin, o.conv.w, s));
+      RLN_TRY(run_wgrad(c, WG_RAW3, w, o.cout, o.cin, o.conv.w, ws));
     }
+    RLN_TRY(wg_end(c));
   } else if (o.type == OP_TD) {
     const Level& sl = c->levels[o.src_level];
     const Level& dl = c->levels[o.dst_level];
@@ -934,7 +1028,9 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
     w.wsize = (long long)o.cout * o.cin;
     w.m_stride = o.cin;
     w.n_stride = 1;
-    RLN_TRY(run_wgrad(c, WG_PW1, w, o.cout, o.cin, o.conv.w, s));
+    RLN_TRY(wg_begin(c, s, &ws));
+    RLN_TRY(run_wgrad(c, WG_PW1, w, o.cout, o.cin, o.conv.w, ws));
+    RLN_TRY(wg_end(c));
   } else {  // OP_TU
     const Level& sl = c->levels[o.src_level];
     const Level& dl = c->levels[o.dst_level];
@@ -992,7 +1088,9 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
     w.wsize = (long long)o.cin * o.cout * 9;
     w.m_stride = 9;                       // m = c_out
     w.n_stride = (long long)o.cout * 9;   // n = c_in
-    RLN_TRY(run_wgrad(c, WG_CONVT, w, o.cout, o.cin, o.conv.w, s));
+    RLN_TRY(wg_begin(c, s, &ws));
+    RLN_TRY(run_wgrad(c, WG_CONVT, w, o.cout, o.cin, o.conv.w, ws));
+    RLN_TRY(wg_end(c));
   }
   return 0;
 }
@@ -1021,7 +1119,18 @@ int rln_create(const rln_config* cfg, rln_ctx** out) {
   return 0;
 }
 
-void rln_destroy(rln_ctx* ctx) { delete ctx; }
+void rln_destroy(rln_ctx* ctx) {
+  if (!ctx) return;
+  if (ctx->side) {
+    (void)hipStreamSynchronize(ctx->side);
+    for (int b = 0; b < 2; ++b) {
+      if (ctx->ev_dy[b]) (void)hipEventDestroy(ctx->ev_dy[b]);
+      if (ctx->ev_wg[b]) (void)hipEventDestroy(ctx->ev_wg[b]);
+    }
+    (void)hipStreamDestroy(ctx->side);
+  }
+  delete ctx;
+}
 
 int rln_num_tensors(const rln_ctx* c) { return (int)c->tensors.size(); }
 int64_t rln_param_count(const rln_ctx* c) { return c->n_param; }
@@ -1157,6 +1266,17 @@ int rln_backward(rln_ctx* c, float loss_scale, int seg_begin, int seg_end, void*
     return fail(RLN_ERR_STATE, "rln_backward needs a training rln_forward followed by a weighted rln_loss");
   if (seg_begin < 0 || seg_end > c->n_seg || seg_begin >= seg_end) return fail(RLN_ERR_ARG, "bad segment range");
   const int N = c->N;
+  // measured on MI355X: no gain (the kernels' LDS footprints do not co-reside on a CU and both are bound by the
+  // memory system), so the concurrent weight-gradient stream is opt-in.
+  if (!c->side && getenv("RLN_SIDE_STREAM")) {
+    hipError_t e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    for (int b = 0; b < 2 && e == hipSuccess; ++b) {
+      e = hipEventCreateWithFlags(&c->ev_dy[b], hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_wg[b], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) return fail((int)e, "side stream creation failed");
+  }
+  c->use_side = c->side != nullptr;
   if (seg_begin == 0) {
     hipError_t e = hipMemsetAsync(c->S1, 0, sizeof(float) * 2 * c->n_chan, s);
     if (e != hipSuccess) return fail((int)e, "memset failed");
@@ -1180,6 +1300,14 @@ int rln_backward(rln_ctx* c, float loss_scale, int seg_begin, int seg_end, void*
   for (int seg = std::max(seg_begin, 1); seg < seg_end; ++seg) {
     for (int k = (int)c->ops.size() - 1; k >= 0; --k)
       if (c->ops[k].seg == seg) RLN_TRY(bwd_op(c, (size_t)k, s));
+  }
+  // join: everything this call produced (incl. side-stream weight gradients) is ordered before later work on `s`
+  for (int b = 0; b < 2; ++b) {
+    if (c->use_side && c->wg_pending[b]) {
+      hipError_t e = hipStreamWaitEvent(s, c->ev_wg[b], 0);
+      if (e != hipSuccess) return fail((int)e, "hipStreamWaitEvent failed");
+      c->wg_pending[b] = false;
+    }
   }
   return 0;
 }
@@ -1279,6 +1407,15 @@ int rln_profile_enable(rln_ctx* c, int on) {
   }
   c->prof.entries.clear();
   c->prof.on = on != 0;
+  return 0;
+}
+
+// diagnostic: copies the 8 in-kernel phase counters (RLN_DBG=16) to the host and clears them
+int rln_debug_read_stamps(unsigned long long* out8) {
+  unsigned long long* d = igemm_debug_buffer();
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpy(out8, d, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  (void)hipMemset(d, 0, 8 * sizeof(unsigned long long));
   return 0;
 }
 

@@ -42,6 +42,11 @@ struct GradFinParams {
 int grad_finalize(const GradFinParams& p, int N, long long* rows, hipStream_t s);
 long long grad_finalize_rows(int N, int Hd, int Wd);
 
+// split-K finish: out[n][j][p] = (sum_s part[s][n][j][p] + bias[j]) * nscale[n][j]; stats partial [N*gx][J][2]
+int splitk_finish(const float* part, int nsplit, long long split_stride, int N, int J, int HW, const float* bias,
+                  const float* nscale, float* out, long long out_ns, float* stat_partial, long long* nblk,
+                  hipStream_t s);
+
 // dst[e] = sum_r src[r*len + e]   (fixed order)
 int reduce_rows(const float* src, long long rows, long long len, float* dst, hipStream_t s);
 

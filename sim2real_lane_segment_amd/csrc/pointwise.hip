@@ -186,6 +186,47 @@ int grad_finalize(const GradFinParams& p, int N, long long* rows, hipStream_t s)
   RLN_LAUNCH_CHECK();
 }
 
+__global__ __launch_bounds__(256) void splitk_finish_k(const float* __restrict__ part, int nsplit, long long split_stride,
+                                                       int J, int HW, const float* __restrict__ bias,
+                                                       const float* __restrict__ nscale, float* out, long long out_ns,
+                                                       float* stat_partial) {
+  const int j = blockIdx.y, n = blockIdx.z;
+  const int px = blockIdx.x * 256 + threadIdx.x;
+  float v = 0.f;
+  if (px < HW) {
+    const float* pp = part + ((long long)n * J + j) * HW + px;
+    float acc = 0.f;
+    for (int s = 0; s < nsplit; ++s) acc += pp[(long long)s * split_stride];
+    const float sc = nscale ? nscale[(long long)n * J + j] : 1.f;
+    v = (acc + (bias ? bias[j] : 0.f)) * sc;
+    out[(long long)n * out_ns + (long long)j * HW + px] = v;
+  }
+  if (stat_partial != nullptr) {
+    __shared__ float red[4][2];
+    const float a1 = wave_sum64(v), a2 = wave_sum64(v * v);
+    if ((threadIdx.x & 63) == 0) {
+      red[threadIdx.x >> 6][0] = a1;
+      red[threadIdx.x >> 6][1] = a2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const long long row = (long long)n * gridDim.x + blockIdx.x;
+      stat_partial[(row * J + j) * 2 + 0] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+      stat_partial[(row * J + j) * 2 + 1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+    }
+  }
+}
+
+int splitk_finish(const float* part, int nsplit, long long split_stride, int N, int J, int HW, const float* bias,
+                  const float* nscale, float* out, long long out_ns, float* stat_partial, long long* nblk,
+                  hipStream_t s) {
+  const int gx = (HW + 255) / 256;
+  if (nblk) *nblk = (long long)gx * N;
+  hipLaunchKernelGGL(splitk_finish_k, dim3(gx, J, N), dim3(256), 0, s, part, nsplit, split_stride, J, HW, bias, nscale,
+                     out, out_ns, stat_partial);
+  RLN_LAUNCH_CHECK();
+}
+
 __global__ __launch_bounds__(256) void reduce_rows_k(const float* __restrict__ src, long long rows, long long len,
                                                      float* dst) {
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
