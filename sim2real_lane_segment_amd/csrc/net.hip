@@ -416,12 +416,14 @@ void level_dims(const rln_ctx* c, int h, int w, std::vector<int>& hs, std::vecto
   }
 }
 
-// forward split-K factor of a dense layer: small levels do not fill the chip with one block per tile
-int dense_fwd_split(long long blocks, int cin) {
-  if (blocks >= 256 || getenv("RLN_NO_SPLITK")) return 1;
+// Forward split-K factor of a dense layer.  Small levels do not fill the chip with one block per tile, so the
+// input-channel loop is split over blocks.  The factor depends on the level's pixel count ONLY (not on the batch
+// size), so a sample's result does not depend on which batch it is evaluated in.
+int dense_fwd_split(int hw, int cin) {
+  if (hw > 512 || hw <= 0 || getenv("RLN_NO_SPLITK")) return 1;
   const int nchunk = (cin + 15) / 16;
-  const long long want = (512 + blocks - 1) / blocks;
-  return (int)std::max<long long>(1, std::min<long long>(want, nchunk));
+  const int want = hw <= 128 ? 8 : 4;
+  return std::max(1, std::min(want, nchunk));
 }
 
 long long wgrad_chunks(long long total_items, int mgroups, int ngroups, int* ipc) {
@@ -462,7 +464,7 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
       const size_t blocks = (size_t)n * ((Hd + th - 1) / th) * ((Wd + tw - 1) / tw);
       stat_max = std::max(stat_max, blocks * o.cout * 2);
       if (o.type == OP_DENSE) {
-        const int sp = dense_fwd_split((long long)blocks, o.cin);
+        const int sp = dense_fwd_split(Hd * Wd, o.cin);
         if (sp > 1) {
           fs_max = std::max(fs_max, (size_t)sp * n * o.cout * Hd * Wd);
           stat_max = std::max(stat_max, (size_t)n * ((Hd * Wd + 255) / 256) * o.cout * 2);
@@ -707,7 +709,7 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
     const int cls = o.type == OP_FIRST ? PC_FIRST_FWD : o.type == OP_DENSE ? PC_DENSE_FWD
                     : o.type == OP_TD  ? PC_TD_FWD : PC_TU_FWD;
     ProfScope ps(c, cls, flops, bytes, s);
-    const int sp = (o.type == OP_DENSE) ? dense_fwd_split(igemm_stat_blocks(p, N), o.cin) : 1;
+    const int sp = (o.type == OP_DENSE) ? dense_fwd_split(dl.H * dl.W, o.cin) : 1;
     if (sp > 1) {  // split-K: raw partial sums to scratch, then bias / dropout scale / statistics in the finish pass
       IgemmParams q = p;
       const int HW = dl.H * dl.W;
@@ -1170,6 +1172,7 @@ int rln_bind_params(rln_ctx* c, float* params, float* grads, float* bn_running, 
 }
 
 size_t rln_workspace_bytes(const rln_ctx* c, int n, int h, int w, int with_backward) {
+  if (n < 1 || h < 1 || w < 1 || (h >> c->cfg.n_down) < 1 || (w >> c->cfg.n_down) < 1) return 0;  // rln_set_workspace reports
   return carve(const_cast<rln_ctx*>(c), nullptr, n, h, w, with_backward, false);
 }
 
@@ -1177,7 +1180,7 @@ int rln_set_workspace(rln_ctx* c, void* ws, size_t bytes, int n, int h, int w, i
   if (n < 1 || h < 1 || w < 1) return fail(RLN_ERR_ARG, "bad geometry %dx%dx%d", n, h, w);
   if ((h >> c->cfg.n_down) < 1 || (w >> c->cfg.n_down) < 1)
     return fail(RLN_ERR_ARG, "input %dx%d too small for %d poolings (Output size is too small)", h, w, c->cfg.n_down);
-  const size_t need = carve(c, nullptr, n, h, w, with_backward, false);
+  const size_t need = rln_workspace_bytes(c, n, h, w, with_backward);
   if (!ws || bytes < need) return fail(RLN_ERR_WORKSPACE, "workspace of %zu bytes needed, got %zu", need, bytes);
   if (((uintptr_t)ws) & 255) return fail(RLN_ERR_WORKSPACE, "workspace must be 256-byte aligned");
   carve(c, ws, n, h, w, with_backward, true);

@@ -87,6 +87,7 @@ def test_error_conventions():
     assert need > 2 * 288 * 120 * 160 * 4 * 2
     assert lib.rln_workspace_bytes(eng.ctx, 2, 120, 160, 0) < need
     # five floor-poolings do not fit into 16x16 ("Output size is too small" in the reference)
+    assert lib.rln_workspace_bytes(eng.ctx, 1, 16, 16, 0) == 0
     assert lib.rln_set_workspace(eng.ctx, ctypes.c_void_p(256), 1 << 40, 1, 16, 16, 0) == -1
     assert lib.rln_set_workspace(eng.ctx, None, 0, 2, 120, 160, 1) == -3
     with pytest.raises(RuntimeError):
