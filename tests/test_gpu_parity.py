@@ -230,7 +230,7 @@ def test_config0_batch8_train_step_vs_oracle():
     out, _, _ = eng.loss(probs, y.cuda(), weighted=True)
     eng.backward(1.0)
     torch.cuda.synchronize()
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    torch.set_num_threads(min(16, max(1, len(os.sched_getaffinity(0)))))
     ts = O.TrainState({k: v.clone() for k, v in st.items()})
     loss, acc, grads, probs_ref = O.train_step(ts, x, y, cfg, scales, apply_update=False)
     assert abs(float(out[0]) - float(loss)) < 2e-4
