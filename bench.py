@@ -113,13 +113,24 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--buckets", type=int, default=4)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="single-GPU plumbing check: 1-rank RCCL process group + the bucketed all-reduce path")
     args = ap.parse_args()
+
+    # Libraries (RCCL prints a banner at communicator creation) must not pollute stdout: the contract is ONE JSON
+    # line there.  Everything until the final print goes to stderr at the file-descriptor level.
+    sys.stdout.flush()
+    saved_stdout_fd = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
@@ -134,7 +145,7 @@ def main():
     model = SimpleTrainModule(lr=1e-3, lrRatio=1e3, decay=1e-4, num_cls=4).to(dev)  # random init, FCDenseNet67
     model.train()
     eng = model._rln_sync()
-    stepper = TrainStepper(eng, lr=1e-3, weight_decay=1e-4, n_buckets=args.buckets)
+    stepper = TrainStepper(eng, lr=1e-3, weight_decay=1e-4, n_buckets=args.buckets, force_collectives=args.force_dist)
     stepper.broadcast_parameters()
 
     B = args.batch
@@ -221,8 +232,11 @@ def main():
                 for p in sorted(timed, key=lambda p: -p["ms"])]
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
+        sys.stdout.flush()
+        os.dup2(saved_stdout_fd, 1)
         print(json.dumps(result), flush=True)
-    if world > 1:
+        os.dup2(2, 1)
+    if world > 1 or args.force_dist:
         dist.destroy_process_group()
 
 

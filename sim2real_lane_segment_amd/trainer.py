@@ -35,16 +35,18 @@ class BucketedGradReducer:
     """Runs ``run_segments(seg_begin, seg_end)`` bucket by bucket and overlaps the all-reduce of each finished
     gradient slice with the next bucket's backward.  Works on any flat tensor (CPU/gloo in tests)."""
 
-    def __init__(self, flat_grads: torch.Tensor, seg_ranges, n_buckets=4, group=None):
+    def __init__(self, flat_grads: torch.Tensor, seg_ranges, n_buckets=4, group=None, force_collectives=False):
         self.flat = flat_grads
         self.buckets = plan_buckets(seg_ranges, n_buckets)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        # force_collectives: run the bucketed all-reduce path even with one rank (plumbing check on a single GPU)
+        self.force = bool(force_collectives) and dist.is_available() and dist.is_initialized()
         self.cuda = flat_grads.is_cuda
         self.comm_stream = torch.cuda.Stream(device=flat_grads.device) if self.cuda else None
 
     def backward_and_reduce(self, run_segments: Callable[[int, int], None]):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             run_segments(0, self.buckets[-1][1])
             return
         handles = []
@@ -69,18 +71,21 @@ class BucketedGradReducer:
 class TrainStepper:
     """Fast path used by bench.py and scripts: bypasses autograd, drives the engine directly."""
 
-    def __init__(self, engine, lr=1e-3, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8, n_buckets=4):
+    def __init__(self, engine, lr=1e-3, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8, n_buckets=4,
+                 force_collectives=False):
         self.eng = engine
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         self.m = torch.zeros_like(engine.params)
         self.v = torch.zeros_like(engine.params)
         self.step_no = 0
-        self.reducer = BucketedGradReducer(engine.grads, engine.seg_ranges, n_buckets)
+        self.reducer = BucketedGradReducer(engine.grads, engine.seg_ranges, n_buckets,
+                                           force_collectives=force_collectives)
         self.world = self.reducer.world
+        self.force = self.reducer.force
 
     def broadcast_parameters(self):
         """DDP's one-time parameter broadcast from rank 0."""
-        if self.world > 1:
+        if self.world > 1 or self.force:
             dist.broadcast(self.eng.params, 0)
             dist.broadcast(self.eng.bnrun, 0)
 
