@@ -117,6 +117,17 @@ int rln_classifier_forward(rln_ctx* ctx, const float* feat, int n, int h, int w,
 int rln_loss(rln_ctx* ctx, const float* probs, const int64_t* y, int n, int h, int w, int weighted, float* out,
              int64_t* argmax_out, int64_t* confusion_out, void* stream);
 
+/* ---- MME unlabelled branch (MMETrainingModule.py:10-11,28-33): out[0] = lamda * mean_pixels(sum_k p*log(p+1e-5)).
+ * A following rln_backward differentiates THIS loss and applies the gradient reversal of
+ * GradReverse (tiramisu.py:7-18) between classifier and feature extractor: classifier gradients keep their sign,
+ * everything upstream of the features is negated. */
+int rln_entropy_loss(rln_ctx* ctx, const float* probs, int n, int h, int w, float lamda, float* out, void* stream);
+
+/* torch.optim.SGD(momentum, nesterov=True, dampening=0, weight_decay) on a flat range, as configured in
+ * MMETrainingModule.py:17-20 (one call per parameter group; first_step=1 initialises the momentum buffer). */
+int rln_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t count, float lr, float momentum,
+                 float weight_decay, int first_step, float grad_scale, void* stream);
+
 /* ---- backward of loss∘classifier∘featureExtractor for the last training rln_forward + rln_loss(weighted)
  * (autograd of the torch graph in the reference).  Fills the bound gradient arena (overwrites).
  * The plan is cut into rln_backward_segments() segments that complete contiguous slices of the gradient

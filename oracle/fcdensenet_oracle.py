@@ -387,6 +387,46 @@ def cosine_lr(epoch: int, base_lr: float, lr_ratio: float, t_max: int = 25) -> f
     return eta_min + (base_lr - eta_min) * (1 + math.cos(math.pi * epoch / t_max)) / 2
 
 
+class _GradReverse(torch.autograd.Function):
+    """GradReverse (models/FCDenseNet/tiramisu.py:7-18): identity forward, negated gradient."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.neg()
+
+
+def adentropy(probs: Tensor, lamda: float = 1.0) -> Tensor:
+    """trainingModules/MMETrainingModule.py:10-11."""
+    return lamda * torch.mean(torch.sum(probs * torch.log(probs + 1e-5), 1))
+
+
+def mme_unlabelled_step(st: Dict[str, Tensor], x: Tensor, cfg: NetConfig, drop_scales, lamda: float = 0.1):
+    """MMETrainingModule.training_step with optimizer_idx == 0 (MMETrainingModule.py:28-33): features ->
+    grad_reverse -> classifier -> adentropy(lamda).  Returns (loss, grads dict)."""
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in st.items() if is_param(k)}
+    work = dict(st)
+    work.update(params)
+    feat = features_forward(work, x, cfg, True, drop_scales, {})
+    probs = classifier_forward(work, _GradReverse.apply(feat), cfg)
+    loss = adentropy(probs, lamda)
+    grads = torch.autograd.grad(loss, list(params.values()))
+    return loss.detach(), {k: g for k, g in zip(params.keys(), grads)}
+
+
+def sgd_nesterov_step(p: Tensor, g: Tensor, buf: Optional[Tensor], lr: float, momentum: float = 0.9,
+                      weight_decay: float = 1e-4):
+    """torch.optim.SGD(momentum, nesterov=True, dampening=0) single-tensor update as configured by
+    MMETrainingModule.py:17-20.  Returns the new momentum buffer."""
+    g = g + weight_decay * p
+    buf = g.clone() if buf is None else buf.mul(momentum).add(g)
+    p.sub_(lr * (g + momentum * buf))
+    return buf
+
+
 def is_param(name: str) -> bool:
     return not (name.endswith("running_mean") or name.endswith("running_var")
                 or name.endswith("num_batches_tracked"))

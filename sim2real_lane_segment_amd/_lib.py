@@ -48,6 +48,9 @@ _PROTOS = {
     "rln_classifier_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "rln_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                          c_void_p]),
+    "rln_entropy_loss": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "rln_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_int, c_float,
+                             c_void_p]),
     "rln_backward_segments": (c_int, [c_void_p]),
     "rln_backward_segment_range": (c_int, [c_void_p, c_int, POINTER(c_int64), POINTER(c_int64)]),
     "rln_backward": (c_int, [c_void_p, c_float, c_int, c_int, c_void_p]),

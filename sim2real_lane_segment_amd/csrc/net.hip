@@ -155,6 +155,8 @@ struct rln_ctx {
   const float* last_x = nullptr;
   const int64_t* last_y = nullptr;
   int have_train_fwd = 0, have_loss = 0;
+  int loss_mode = 0;      // 0: weighted CE (rln_loss), 1: entropy with gradient reversal (rln_entropy_loss)
+  float loss_lamda = 0.f;
   const float* last_scales = nullptr;
 };
 
@@ -1250,6 +1252,25 @@ int rln_loss(rln_ctx* c, const float* probs, const int64_t* y, int n, int h, int
   }
   c->last_y = y;
   c->have_loss = weighted ? 1 : 0;
+  c->loss_mode = 0;
+  return 0;
+}
+
+int rln_entropy_loss(rln_ctx* c, const float* probs, int n, int h, int w, float lamda, float* out, void* stream) {
+  if (!c->loss.counts || n != c->N || h != c->H || w != c->W)
+    return fail(RLN_ERR_WORKSPACE, "workspace not set for geometry %dx%dx%d", n, h, w);
+  RLN_TRY(entropy_forward(probs, n, c->cfg.n_classes, h * w, lamda, c->loss, out, (hipStream_t)stream));
+  c->have_loss = 1;
+  c->loss_mode = 1;
+  c->loss_lamda = lamda;
+  return 0;
+}
+
+int rln_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t count, float lr, float momentum,
+                 float weight_decay, int first_step, float grad_scale, void* stream) {
+  if (!params || !grads || !momentum_buf || count < 0) return fail(RLN_ERR_ARG, "bad argument");
+  RLN_TRY(sgd_nesterov(params, grads, momentum_buf, count, lr, momentum, weight_decay, first_step, grad_scale,
+                       (hipStream_t)stream));
   return 0;
 }
 
@@ -1266,7 +1287,8 @@ int rln_backward(rln_ctx* c, float loss_scale, int seg_begin, int seg_end, void*
   hipStream_t s = (hipStream_t)stream;
   if (!c->with_bwd || !c->grads) return fail(RLN_ERR_STATE, "no gradient arena / backward workspace");
   if (!c->have_train_fwd || !c->have_loss)
-    return fail(RLN_ERR_STATE, "rln_backward needs a training rln_forward followed by a weighted rln_loss");
+    return fail(RLN_ERR_STATE, "rln_backward needs a training rln_forward followed by rln_loss(weighted) or "
+                               "rln_entropy_loss");
   if (seg_begin < 0 || seg_end > c->n_seg || seg_begin >= seg_end) return fail(RLN_ERR_ARG, "bad segment range");
   const int N = c->N;
   // measured on MI355X: no gain (the kernels' LDS footprints do not co-reside on a CU and both are bound by the
@@ -1284,6 +1306,10 @@ int rln_backward(rln_ctx* c, float loss_scale, int seg_begin, int seg_end, void*
     hipError_t e = hipMemsetAsync(c->S1, 0, sizeof(float) * 2 * c->n_chan, s);
     if (e != hipSuccess) return fail((int)e, "memset failed");
     HeadBwdParams q;
+    q.mode = c->loss_mode;
+    q.lamda = c->loss_lamda;
+    q.inv_count = (float)(1.0 / ((double)N * c->H * c->W));
+    q.feat_sign = c->loss_mode == 1 ? -1.f : 1.f;  // grad_reverse between features and classifier (MME)
     q.h = head_params(c);
     q.y = (const long long*)c->last_y;
     q.lossres = c->loss.result;

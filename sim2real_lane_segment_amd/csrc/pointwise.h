@@ -72,7 +72,18 @@ int loss_forward(const float* probs, const long long* y, int N, int ncls, int HW
                  float* out, long long* argmax_out, long long* confusion_out, hipStream_t s);
 long long loss_blocks(long long npix);
 
+// adentropy (MMETrainingModule.py:10-11): out[0] = lamda * mean_pixels(sum_k p*log(p+1e-5))
+int entropy_forward(const float* probs, int N, int ncls, int HW, float lamda, const LossScratch& sc, float* out,
+                    hipStream_t s);
+// torch.optim.SGD with momentum + nesterov (dampening 0) on a flat range
+int sgd_nesterov(float* p, const float* g, float* buf, long long count, float lr, float momentum, float wd,
+                 int first_step, float grad_scale, hipStream_t s);
+
 struct HeadBwdParams {
+  int mode;        // 0: class-weighted CE on probabilities, 1: entropy (adentropy)
+  float lamda;     // entropy weight
+  float inv_count; // 1 / (N*H*W)
+  float feat_sign; // -1 when a gradient-reversal layer sits between features and classifier
   HeadParams h;
   const long long* y;
   const float* lossres;  // LossScratch.result

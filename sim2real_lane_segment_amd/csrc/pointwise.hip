@@ -554,16 +554,25 @@ __global__ __launch_bounds__(256) void head_bwd_data_k(const HeadBwdParams q) {
 #pragma unroll
     for (int k = 0; k < NC; ++k) qq[k] = pr[k];
     softmax_nc<NC>(qq, p.ncls);
-    const long long lab = q.y[(long long)n * p.HW + px];
-    float wy = 0.f;
-    if (lab >= 0 && lab < p.ncls) wy = q.lossres[4 + (int)lab];
-    const float coef = q.loss_scale * wy / q.lossres[1];
     float gp[NC];
     float dot = 0.f;
+    if (q.mode == 0) {
+      const long long lab = q.y[(long long)n * p.HW + px];
+      float wy = 0.f;
+      if (lab >= 0 && lab < p.ncls) wy = q.lossres[4 + (int)lab];
+      const float coef = q.loss_scale * wy / q.lossres[1];
 #pragma unroll
-    for (int k = 0; k < NC; ++k) {
-      gp[k] = (k < p.ncls) ? coef * (qq[k] - ((k == (int)lab) ? 1.f : 0.f)) : 0.f;
-      dot = fmaf(pr[k], gp[k], dot);
+      for (int k = 0; k < NC; ++k) {
+        gp[k] = (k < p.ncls) ? coef * (qq[k] - ((k == (int)lab) ? 1.f : 0.f)) : 0.f;
+        dot = fmaf(pr[k], gp[k], dot);
+      }
+    } else {  // d/dp of lamda * mean(sum_k p*log(p+1e-5))
+      const float coef = q.loss_scale * q.lamda * q.inv_count;
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        gp[k] = (k < p.ncls) ? coef * (logf(pr[k] + 1e-5f) + pr[k] / (pr[k] + 1e-5f)) : 0.f;
+        dot = fmaf(pr[k], gp[k], dot);
+      }
     }
     float t = 0.f;
 #pragma unroll
@@ -579,7 +588,7 @@ __global__ __launch_bounds__(256) void head_bwd_data_k(const HeadBwdParams q) {
       float gxn = 0.f;
 #pragma unroll
       for (int k = 0; k < NC; ++k) gxn = fmaf(wt[c * NC + k], gl[k], gxn);
-      const float gx = (gxn - x * inv * t) * inv;
+      const float gx = q.feat_sign * (gxn - x * inv * t) * inv;
       gout[(long long)c * p.HW] = gx / q.invstd[c];
     }
 #pragma unroll
@@ -653,6 +662,78 @@ int head_backward_weight(const HeadParams& p, int N, const float* glin, float* p
   } else {
     hipLaunchKernelGGL(head_bwd_weight_k<16>, grid, dim3(256), 0, s, p, glin, partial);
   }
+  RLN_LAUNCH_CHECK();
+}
+
+// adentropy forward
+template <int NC>
+__global__ __launch_bounds__(256) void entropy_k(const float* __restrict__ probs, int ncls, long long HW, long long npix,
+                                                 float* partial) {
+  float acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < LOSS_PIX_PER_BLOCK / 256; ++i) {
+    const long long g = (long long)blockIdx.x * LOSS_PIX_PER_BLOCK + i * 256 + threadIdx.x;
+    if (g < npix) {
+      const long long n = g / HW, px = g - n * HW;
+#pragma unroll
+      for (int k = 0; k < NC; ++k)
+        if (k < ncls) {
+          const float pk = probs[(n * ncls + k) * HW + px];
+          acc += pk * logf(pk + 1e-5f);
+        }
+    }
+  }
+  __shared__ float red[4];
+  acc = wave_sum64(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[(long long)blockIdx.x * 4] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void entropy_finalize_k(const float* __restrict__ partial, long long nblk, double scale,
+                                                          float* out) {
+  double a = 0.0;
+  for (long long b = threadIdx.x; b < nblk; b += 256) a += (double)partial[b * 4];
+  __shared__ double red[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (float)((red[0] + red[1] + red[2] + red[3]) * scale);
+}
+
+int entropy_forward(const float* probs, int N, int ncls, int HW, float lamda, const LossScratch& sc, float* out,
+                    hipStream_t s) {
+  if (ncls > 16 || ncls < 1) return -4;
+  const long long npix = (long long)N * HW;
+  const long long nblk = loss_blocks(npix);
+  if (ncls <= 4) {
+    hipLaunchKernelGGL(entropy_k<4>, dim3((unsigned)nblk), dim3(256), 0, s, probs, ncls, (long long)HW, npix, sc.partial);
+  } else if (ncls <= 8) {
+    hipLaunchKernelGGL(entropy_k<8>, dim3((unsigned)nblk), dim3(256), 0, s, probs, ncls, (long long)HW, npix, sc.partial);
+  } else {
+    hipLaunchKernelGGL(entropy_k<16>, dim3((unsigned)nblk), dim3(256), 0, s, probs, ncls, (long long)HW, npix, sc.partial);
+  }
+  hipLaunchKernelGGL(entropy_finalize_k, dim3(1), dim3(256), 0, s, sc.partial, nblk, (double)lamda / (double)npix, out);
+  RLN_LAUNCH_CHECK();
+}
+
+__global__ __launch_bounds__(256) void sgd_nesterov_k(float* __restrict__ p, const float* __restrict__ g,
+                                                      float* __restrict__ buf, long long count, float lr, float mu,
+                                                      float wd, int first_step, float grad_scale) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  const float pi = p[i];
+  const float gi = g[i] * grad_scale + wd * pi;
+  const float bi = first_step ? gi : fmaf(mu, buf[i], gi);
+  buf[i] = bi;
+  p[i] = pi - lr * (gi + mu * bi);
+}
+
+int sgd_nesterov(float* p, const float* g, float* buf, long long count, float lr, float momentum, float wd,
+                 int first_step, float grad_scale, hipStream_t s) {
+  hipLaunchKernelGGL(sgd_nesterov_k, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, p, g, buf, count, lr,
+                     momentum, wd, first_step, grad_scale);
   RLN_LAUNCH_CHECK();
 }
 

@@ -204,6 +204,23 @@ class Engine:
         self._keep.append(y)
         return out, am, conf
 
+    def entropy_loss(self, probs: torch.Tensor, lamda: float):
+        """adentropy of the MME unlabelled branch; a following backward() applies the gradient reversal."""
+        self._require_gpu()
+        n, k, h, w = probs.shape
+        out = torch.empty(1, dtype=torch.float32, device=self.device)
+        _lib.check(self.L.rln_entropy_loss(self.ctx, _ptr(probs), n, h, w, float(lamda), _ptr(out), _stream()),
+                   "rln_entropy_loss")
+        return out
+
+    def sgd_step(self, momentum_buf, lo, hi, lr, momentum, weight_decay, first_step, grads_ptr=None, grad_scale=1.0):
+        """Nesterov SGD on the arena range [lo, hi) (one parameter group)."""
+        self._require_gpu()
+        gptr = ctypes.c_void_p((grads_ptr if grads_ptr is not None else self.grads.data_ptr()) + 4 * lo)
+        _lib.check(self.L.rln_sgd_step(_ptr(self.params[lo:hi]), gptr, _ptr(momentum_buf[lo:hi]), hi - lo, float(lr),
+                                       float(momentum), float(weight_decay), int(first_step), float(grad_scale),
+                                       _stream()), "rln_sgd_step")
+
     def backward(self, loss_scale: float = 1.0, seg_begin: int = 0, seg_end: Optional[int] = None):
         self._require_gpu()
         if seg_end is None:

@@ -109,9 +109,14 @@ class TrainStepFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, owner, x, y, drop_scales, seed, *params):
+        """y: int64 labels -> class-weighted CE step; y: float lamda -> MME unlabelled step (entropy of the
+        classifier output behind a gradient-reversal layer, MMETrainingModule.py:28-33)."""
         eng = owner._rln_sync()
         probs, _ = eng.forward(x, training=True, with_backward=True, drop_scales=drop_scales, seed=seed)
-        out, _, _ = eng.loss(probs, y, weighted=True)
+        if isinstance(y, float):
+            out = eng.entropy_loss(probs, y)
+        else:
+            out, _, _ = eng.loss(probs, y, weighted=True)
         ctx.owner = owner
         ctx.n_params = len(params)
         loss = out[0].clone()
@@ -193,3 +198,59 @@ class FusedAdamW(torch.optim.Optimizer):
             self._step = int(extra["step"])
             self.exp_avg.copy_(extra["exp_avg"])
             self.exp_avg_sq.copy_(extra["exp_avg_sq"])
+
+
+def _flat_grad_base(eng, params, names, offs):
+    """Device address of a flat gradient buffer in arena order if every .grad is a slice of one, else None."""
+    g0 = params[0].grad
+    if g0 is None or g0.dtype != torch.float32 or g0.device != eng.params.device:
+        return None
+    base = g0.data_ptr() - 4 * offs[names[0]]
+    ok = all(p.grad is not None and p.grad.data_ptr() == base + 4 * offs[n] for p, n in zip(params, names))
+    return base if ok else None
+
+
+class FusedSGD(torch.optim.Optimizer):
+    """torch.optim.SGD(momentum=0.9, nesterov=True, weight_decay) with the two parameter groups of
+    MMETrainingModule.py:17-20 (feature extractor at lr/3, classifier at lr), one HIP kernel per group over
+    the flat arena (the groups are contiguous arena ranges: the classifier is laid out last)."""
+
+    def __init__(self, owner: EngineOwner, lr_feature, lr_classifier, momentum=0.9, weight_decay=0.0):
+        self.owner = owner
+        params = owner._rln_params_in_arena_order()
+        names = owner._rln_param_names
+        fe = [p for p, n in zip(params, names) if n.startswith("featureExtractor.")]
+        cl = [p for p, n in zip(params, names) if n.startswith("classifier.")]
+        defaults = dict(lr=lr_classifier, momentum=momentum, weight_decay=weight_decay, nesterov=True)
+        super().__init__([{"params": fe, "lr": lr_feature}, {"params": cl, "lr": lr_classifier}], defaults)
+        eng = owner._rln_engine
+        self.split = owner._rln_param_offsets["classifier.finalConv.weight"] if cl else eng.n_param
+        self.buf = torch.zeros_like(eng.params)
+        self._first = True
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        eng = self.owner._rln_sync()
+        if self.buf.device != eng.params.device:
+            self.buf = self.buf.to(eng.params.device)
+        names = self.owner._rln_param_names
+        offs = self.owner._rln_param_offsets
+        params = [p for g in self.param_groups for p in g["params"]]
+        base = _flat_grad_base(eng, params, names, offs)
+        if base is None:
+            for p, name in zip(params, names):
+                gv = eng.grad_views[name]
+                if p.grad is None:
+                    gv.zero_()
+                elif p.grad.data_ptr() != gv.data_ptr():
+                    gv.copy_(p.grad)
+            base = eng.grads.data_ptr()
+        for g, (lo, hi) in zip(self.param_groups, [(0, self.split), (self.split, eng.n_param)]):
+            if hi > lo:
+                eng.sgd_step(self.buf, lo, hi, g["lr"], g["momentum"], g["weight_decay"], self._first, grads_ptr=base)
+        self._first = False
+        return loss

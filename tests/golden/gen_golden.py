@@ -247,6 +247,43 @@ def gen_fcd67_train(name, n, h, w, seed, steps):
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
 
 
+def gen_mme(name, cfg, n, h, w, seed):
+    """MMETrainingModule.training_step, verbatim, for both optimizer indices on a reduced net, followed by one
+    step of the optimizers the reference configures (SGD-nesterov with two lr groups, AdamW)."""
+    from trainingModules.MMETrainingModule import MMETrainingModule
+    st = O.init_state(cfg, seed)
+    net = build_reference(cfg, st)
+    mod = MMETrainingModule.__new__(MMETrainingModule)
+    torch.nn.Module.__init__(mod)
+    mod.featureExtractor, mod.classifier = net.featureExtractor, net.classifier
+    mod.lr, mod.decay, mod.lrRatio, mod.num_cls = 1e-3, 1e-4, 1e3, cfg.n_classes
+    mod.train()
+    (optG, optF), _ = mod.configure_optimizers()
+    xl, y = synth_batch(n, h, w, cfg.n_classes, seed + 1)
+    xu, _ = synth_batch(n, h, w, cfg.n_classes, seed + 5)
+    out = dict(cfg_to_arrays(cfg), n=n, h=h, w=w, seed=seed)
+    named = dict(mod.named_parameters())
+    # optimizer_idx 0: unlabelled -> grad_reverse -> classifier -> adentropy(0.1)
+    scales0 = O.make_drop_scales(cfg, n, seed + 2)
+    with DropInjector() as inj:
+        inj.scales = scales0
+        loss0 = mod.training_step((xl, xu, y, None), 0, optimizer_idx=0)
+    mod.zero_grad()
+    loss0.backward()
+    out["loss0"] = np.float32(loss0.item())
+    for k, p in named.items():
+        out["grad0/" + k] = p.grad.detach().numpy().copy()
+    optG.step()
+    for k, p in named.items():
+        out["param_after_sgd/" + k] = p.detach().numpy().copy()
+    # second SGD step with the same gradients exercises the momentum buffer
+    optG.step()
+    for k, p in named.items():
+        out["param_after_sgd2/" + k] = p.detach().numpy().copy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "loss0", float(loss0))
+
+
 def gen_misc(name):
     """Third-party arithmetic at the reference's call sites: AdamW(lr,weight_decay) 3 steps,
     CosineAnnealingLR(25, eta_min=lr/lrRatio) table, getClassWeight incl. an absent class."""
@@ -283,7 +320,7 @@ def main():
     _install_lightning_stub()
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["misc", "tiny", "tiny_odd", "g16", "g16_absent", "fcd67_eval", "fcd67_eval480",
+    which = sys.argv[1:] or ["misc", "mme", "tiny", "tiny_odd", "g16", "g16_absent", "fcd67_eval", "fcd67_eval480",
                              "fcd67_train"]
     tiny = O.NetConfig(down_blocks=(2, 2), up_blocks=(2, 2), bottleneck_layers=2, growth_rate=4,
                        out_chans_first_conv=8, n_classes=4)
@@ -291,6 +328,8 @@ def main():
                       out_chans_first_conv=48, n_classes=4)
     if "misc" in which:
         gen_misc("misc")
+    if "mme" in which:
+        gen_mme("mme_tiny_40x56", tiny, 2, 40, 56, 800)
     if "tiny" in which:
         gen_small("tiny_40x56", tiny, 2, 40, 56, 100, full=True)
     if "tiny_odd" in which:

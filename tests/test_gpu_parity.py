@@ -310,3 +310,66 @@ def test_module_api_training_step_and_optimizer():
     assert 0 <= float(logs["acc"]) <= 100
     with pytest.raises(RuntimeError):
         model(torch.zeros(1, 3, 16, 16).cuda())  # fewer than 32 px per side: five poolings do not fit
+
+
+def test_mme_unlabelled_step_vs_golden():
+    """MMETrainingModule.training_step(optimizer_idx=0) + the reference's SGD-nesterov groups, reduced net."""
+    z = load("mme_tiny_40x56")
+    cfg = cfg_from_arrays(z, O.NetConfig)
+    n, h, w, seed = int(z["n"]), int(z["h"]), int(z["w"]), int(z["seed"])
+    st = O.init_state(cfg, seed)
+    xu, _ = synth_batch(n, h, w, cfg.n_classes, seed + 5)
+    scales = O.make_drop_scales(cfg, n, seed + 2)
+    eng = make_engine(cfg, st)
+    probs, _ = eng.forward(xu.cuda(), training=True, with_backward=True, drop_scales=eng.pack_drop_scales(scales))
+    out = eng.entropy_loss(probs, 0.1)
+    eng.backward(1.0)
+    torch.cuda.synchronize()
+    assert abs(float(out[0]) - float(z["loss0"])) < 1e-5
+    bad = []
+    for m in eng.metas:
+        if m.kind == 0:
+            err = rel_err(eng.grad_views[m.name].cpu().numpy(), z["grad0/" + m.name])
+            if not err < 3e-3:
+                bad.append((m.name, err))
+    assert not bad, bad[:10]
+    # SGD on the GPU's own gradients must equal the oracle's formula exactly; vs the reference within grad noise
+    buf = torch.zeros_like(eng.params)
+    split = [mm.offset for mm in eng.metas if mm.name == "classifier.finalConv.weight"][0]
+    g_gpu = {m.name: eng.grad_views[m.name].cpu().clone() for m in eng.metas if m.kind == 0}
+    p_ref = {m.name: eng.views[m.name].cpu().clone() for m in eng.metas if m.kind == 0}
+    bufs = {}
+    for step, key in enumerate(["param_after_sgd/", "param_after_sgd2/"]):
+        eng.sgd_step(buf, 0, split, 1e-3 / 3, 0.9, 1e-4, step == 0)
+        eng.sgd_step(buf, split, eng.n_param, 1e-3, 0.9, 1e-4, step == 0)
+        torch.cuda.synchronize()
+        for m in eng.metas:
+            if m.kind != 0:
+                continue
+            lr = 1e-3 if m.name.startswith("classifier.") else 1e-3 / 3
+            bufs[m.name] = O.sgd_nesterov_step(p_ref[m.name], g_gpu[m.name], bufs.get(m.name), lr, 0.9, 1e-4)
+            np.testing.assert_allclose(eng.views[m.name].cpu().numpy(), p_ref[m.name].numpy(), rtol=1e-5, atol=1e-7)
+            np.testing.assert_allclose(eng.views[m.name].cpu().numpy(), z[key + m.name], rtol=1e-4, atol=2e-6,
+                                       err_msg=m.name)
+
+
+def test_mme_module_api():
+    from sim2real_lane_segment_amd.trainingModules.MMETrainingModule import MMETrainingModule
+    torch.manual_seed(0)
+    model = MMETrainingModule(lr=1e-3, lrRatio=1e3, decay=1e-4, num_cls=4).cuda()
+    model.train()
+    (opt_g, opt_f), (sch_g, sch_f) = model.configure_optimizers()
+    xl, y = synth_batch(2, 64, 96, 4, 3)
+    xu, _ = synth_batch(2, 64, 96, 4, 4)
+    batch = (xl.cuda(), xu.cuda(), y.cuda(), None)
+    w0 = model.classifier.finalConv.weight.detach().clone()
+    loss0 = model.training_step(batch, 0, optimizer_idx=0, seed=1)
+    loss0.backward()
+    opt_g.step()
+    opt_g.zero_grad()
+    loss1 = model.training_step(batch, 0, optimizer_idx=1, seed=2)
+    loss1.backward()
+    opt_f.step()
+    assert float(loss0) < 0 < float(loss1)
+    assert not torch.equal(w0, model.classifier.finalConv.weight.detach())
+    assert torch.isfinite(model.featureExtractor.firstconv.weight).all()

@@ -74,6 +74,8 @@ def test_cli_flags_and_optimizers():
     mm = MMETrainingModule(num_cls=4)
     (og, of), (sg, sf) = mm.configure_optimizers()
     assert len(og.param_groups) == 2 and og.param_groups[0]["lr"] == pytest.approx(1e-3 / 3)
+    assert og.param_groups[1]["lr"] == pytest.approx(1e-3) and og.param_groups[0]["nesterov"]
+    assert sum(p.numel() for p in og.param_groups[1]["params"]) == 4 * 288 + 4
 
 
 def test_no_cpu_fallback_and_errors():

@@ -109,3 +109,24 @@ def test_fcd67_eval_masks():
     np.testing.assert_allclose(got, z["probs_samp"], atol=1e-5)
     got_l = logits.permute(0, 2, 3, 1).reshape(-1, 4)[idx].numpy()
     np.testing.assert_allclose(got_l, z["logits_samp"], atol=1e-4)
+
+
+def test_mme_unlabelled_step_and_sgd():
+    z = load("mme_tiny_40x56")
+    cfg = cfg_from_arrays(z, O.NetConfig)
+    n, h, w, seed = int(z["n"]), int(z["h"]), int(z["w"]), int(z["seed"])
+    st = O.init_state(cfg, seed)
+    xu, _ = synth_batch(n, h, w, cfg.n_classes, seed + 5)
+    scales = O.make_drop_scales(cfg, n, seed + 2)
+    loss, grads = O.mme_unlabelled_step(st, xu, cfg, scales, 0.1)
+    assert abs(float(loss) - float(z["loss0"])) < 1e-6
+    for k, g in grads.items():
+        ref = z["grad0/" + k]
+        np.testing.assert_allclose(g.numpy(), ref, rtol=1e-3, atol=1e-7 + 1e-4 * np.abs(ref).max(), err_msg=k)
+    # two SGD-nesterov steps with the reference's two lr groups (features lr/3, classifier lr)
+    bufs = {}
+    for step, key in enumerate(["param_after_sgd/", "param_after_sgd2/"]):
+        for k in grads:
+            lr = 1e-3 if k.startswith("classifier.") else 1e-3 / 3
+            bufs[k] = O.sgd_nesterov_step(st[k], torch.from_numpy(z["grad0/" + k]), bufs.get(k), lr, 0.9, 1e-4)
+            np.testing.assert_allclose(st[k].numpy(), z[key + k], rtol=1e-5, atol=1e-7, err_msg=k)
