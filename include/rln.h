@@ -166,6 +166,28 @@ int rln_profile_read(rln_ctx* ctx, double* ms, double* flops, double* bytes, int
 /* diagnostic only: in-kernel cycle stamps of the dense forward kernel (enabled by env RLN_DBG=16) */
 int rln_debug_read_stamps(unsigned long long* out8);
 
+/* ---- EncDecNet (models/EncDecNet.py:5-112, legacy secondary model) building blocks ---------------------------
+ * rln_op_conv_act: Conv2d(k in {1,3,7}, padding k/2) + bias + activation (EncDecNet.py:14,31-32);
+ *   act: 0 none, 1 relu, 2 prelu / leaky-relu with slope act_param, 3 sigmoid, 4 tanh;
+ *   stats (optional) = per-channel [sum, sum of squares] of the activated output (BatchNorm batch statistics).
+ * rln_op_bn_affine: BatchNorm2d folded to y = a*x+b from those sums (train; updates running stats) or from the
+ *   running statistics (eval) (EncDecNet.py:19-22,33).
+ * rln_op_bn_drop_maxpool: a*x+b, elementwise Dropout mask (0 or 1/(1-p), may be NULL), MaxPool2d(k, 2, k/2)
+ *   (EncDecNet.py:24-27,68,103-104).  rln_op_bn_drop_upsample2: same prologue, UpsamplingBilinear2d(x2),
+ *   align_corners=True (EncDecNet.py:69,107-108).  rln_op_softmax_channels: Softmax(dim=-3) (EncDecNet.py:97). */
+int rln_op_conv_act(const float* x, int n, int cin, int h, int w, const float* weight, const float* bias, int cout,
+                    int ksize, int act, float act_param, float* out, float* stats, void* workspace,
+                    size_t workspace_bytes, void* stream);
+int rln_op_bn_affine(const float* sums, int c, double count, int training, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float momentum, float eps, float* a, float* b,
+                     void* stream);
+int rln_op_bn_drop_maxpool(const float* x, int n, int c, int h, int w, const float* a, const float* b,
+                           const float* mask, int k, float* out, void* stream);
+int rln_op_bn_drop_upsample2(const float* x, int n, int c, int h, int w, const float* a, const float* b,
+                             const float* mask, float* out, void* stream);
+int rln_op_softmax_channels(const float* x, int n, int c, int hw, float* out, void* stream);
+int rln_op_dropout_mask(float* dst, int64_t count, float keep, uint64_t seed, void* stream);
+
 /* rln_op_classifier: FCDenseNetClassifier.forward on caller-provided weights (tiramisu.py:120-125):
  * out[n,k,p] = softmax_k((sum_c w[k,c]*feat[n,c,p] + b[k]) / T). */
 int rln_op_classifier(const float* feat, int n, int c, int hw, const float* w, const float* b, int ncls, float T,

@@ -67,6 +67,16 @@ _PROTOS = {
     "rln_profile_read": (c_int, [c_void_p, POINTER(ctypes.c_double), POINTER(ctypes.c_double),
                                  POINTER(ctypes.c_double), POINTER(c_int64)]),
     "rln_debug_read_stamps": (c_int, [POINTER(ctypes.c_uint64)]),
+    "rln_op_conv_act": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
+                                c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rln_op_bn_affine": (c_int, [c_void_p, c_int, ctypes.c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "rln_op_bn_drop_maxpool": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                       c_void_p, c_void_p]),
+    "rln_op_bn_drop_upsample2": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p]),
+    "rln_op_softmax_channels": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rln_op_dropout_mask": (c_int, [c_void_p, c_int64, c_float, c_uint64, c_void_p]),
     "rln_op_classifier": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_int,
                                   c_void_p]),
 }

@@ -47,6 +47,8 @@ struct IgemmParams {
   const float* einvstd;
   const float* egamma;
   int acc_lo, acc_hi;  // channels in [acc_lo,acc_hi) accumulate into out, others overwrite
+  int act;             // EPI_STORE activation after bias: 0 none, 1 relu, 2 prelu/leaky(act_param), 3 sigmoid, 4 tanh
+  float act_param;
   int ksplit;          // >1: input-channel chunks split over blockIdx.y; raw partial sums go to out + split*split_stride
   long long split_stride;
   int dbg;             // timing ablations only (RLN_DBG): 1 skip global loads, 2 skip LDS commit, 4 skip MFMA, 16 stamps
@@ -63,6 +65,8 @@ enum IgemmKind {
   IG_DGRAD1 = 4,     // KS1 NT4 PRO_RAW    EPI_DGRAD   transition down data gradient
   IG_S2D3 = 5,       // KS3 NT4 PRO_S2D    EPI_STORE   convT data gradient
   IG_CONV1_BN = 6,   // KS1 NT4 PRO_BNRELU EPI_STORE   1x1 conv without pool (generic / tests)
+  IG_CONV7_RAW = 7,  // KS7 NT1 PRO_RAW    EPI_STORE   EncDecNet 7x7 convolutions
+  IG_CONV1_RAW = 8,  // KS1 NT1 PRO_RAW    EPI_STORE   EncDecNet 1x1 classifier
 };
 
 // tile: 0 -> 8x32, 1 -> 16x16

@@ -52,7 +52,7 @@ struct IgCfg {
 
 // Straight-line MFMA block for one staged 16-channel chunk: every LDS offset is a compile-time constant relative
 // to one per-lane base, so reads shared by several (M-tile, tap) pairs are issued once and carry immediates.
-template <typename C, int NT, int TW, unsigned MASK>
+template <typename C, int NT, int TW, unsigned long long MASK>
 __device__ __forceinline__ void igemm_compute(const float* __restrict__ zbase, const float* __restrict__ wlane,
                                               f32x4 (&acc)[C::MPW][NT]) {
   // one 4-channel group per (rolled) iteration keeps the live LDS fragments small; inside, straight-line code
@@ -62,7 +62,7 @@ __device__ __forceinline__ void igemm_compute(const float* __restrict__ zbase, c
     const float* wk = wlane + kg * C::NS * NT * 64;
 #pragma unroll
     for (int s = 0; s < C::NS; ++s) {
-      if (!((MASK >> s) & 1u)) continue;
+      if (!((MASK >> s) & 1ull)) continue;
       float bw[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) bw[nt] = wk[(s * NT + nt) * 64];
@@ -363,13 +363,13 @@ __global__ __launch_bounds__(256, ((NT == 1 && TH * TW <= 256) ? 4 : 2)) void ig
     // ---- MFMA (channels past K are zero-filled in LDS, so all four 4-channel groups always run) ----
     if constexpr (CLS) {  // ConvTranspose2d output parity class: only the taps with matching parity exist
       switch (cls) {
-        case 0: igemm_compute<C, NT, TW, 0x1Bu>(zbase, wlane, acc); break;
-        case 1: igemm_compute<C, NT, TW, 0x12u>(zbase, wlane, acc); break;
-        case 2: igemm_compute<C, NT, TW, 0x18u>(zbase, wlane, acc); break;
-        default: igemm_compute<C, NT, TW, 0x10u>(zbase, wlane, acc); break;
+        case 0: igemm_compute<C, NT, TW, 0x1Bull>(zbase, wlane, acc); break;
+        case 1: igemm_compute<C, NT, TW, 0x12ull>(zbase, wlane, acc); break;
+        case 2: igemm_compute<C, NT, TW, 0x18ull>(zbase, wlane, acc); break;
+        default: igemm_compute<C, NT, TW, 0x10ull>(zbase, wlane, acc); break;
       }
     } else {
-      igemm_compute<C, NT, TW, (1u << C::NS) - 1u>(zbase, wlane, acc);
+      igemm_compute<C, NT, TW, (1ull << C::NS) - 1ull>(zbase, wlane, acc);
     }
     if (stamps) {
       asm volatile("" ::"v"(acc[0][0][0]));  // keep the MFMAs in front of the stamp
@@ -427,7 +427,16 @@ __global__ __launch_bounds__(256, ((NT == 1 && TH * TW <= 256) ? 4 : 2)) void ig
           const int ox0 = gx * S_ + px;
           float v[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = (acc[m][nt][r] + bias_j) * sc;
+          for (int r = 0; r < 4; ++r) {
+            float t = acc[m][nt][r] + bias_j;
+            if (p.act != 0) {  // uniform; EncDecNet's Conv = conv -> activation (models/EncDecNet.py:29-33)
+              if (p.act == 1) t = fmaxf(t, 0.f);
+              else if (p.act == 2) t = t > 0.f ? t : p.act_param * t;
+              else if (p.act == 3) t = 1.f / (1.f + expf(-t));
+              else t = tanhf(t);
+            }
+            v[r] = t * sc;
+          }
           if (S_ == 1 && p.out_vec && ox0 + 3 < p.Wout) {
             *reinterpret_cast<float4*>(dst + ox0) = make_float4(v[0], v[1], v[2], v[3]);
 #pragma unroll
@@ -682,6 +691,12 @@ int igemm_launch(IgemmKind kind, int tile, const IgemmParams& p, int N, hipStrea
                        : launch_t<1, 4, PRO_RAW, EPI_DGRAD, 16, 16>(p, N, stream);
     case IG_S2D3:
       return launch_t<3, 4, PRO_S2D, EPI_STORE, 8, 16>(p, N, stream);
+    case IG_CONV7_RAW:
+      return tile == 0 ? launch_v<7, 1, PRO_RAW, EPI_STORE, 8, 32, false, false>(p, N, stream)
+                       : launch_v<7, 1, PRO_RAW, EPI_STORE, 16, 16, false, false>(p, N, stream);
+    case IG_CONV1_RAW:
+      return tile == 0 ? launch_v<1, 1, PRO_RAW, EPI_STORE, 8, 32, false, false>(p, N, stream)
+                       : launch_v<1, 1, PRO_RAW, EPI_STORE, 16, 16, false, false>(p, N, stream);
   }
   return -1;
 }
@@ -831,7 +846,7 @@ __global__ __launch_bounds__(256, 3) void dgrad_loop_k(const IgemmParams p) {
     f32x4 acc[MPW][1];
 #pragma unroll
     for (int m = 0; m < MPW; ++m) acc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    igemm_compute<C, 1, TW, 0x1FFu>(zbase, wcur + lane, acc);
+    igemm_compute<C, 1, TW, 0x1FFull>(zbase, wcur + lane, acc);
 
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll

@@ -1472,6 +1472,87 @@ int rln_profile_read(rln_ctx* c, double* ms, double* flops, double* bytes, int64
   return 0;
 }
 
+// ---- EncDecNet building blocks (models/EncDecNet.py) ------------------------------------------------------
+int rln_op_conv_act(const float* x, int n, int cin, int h, int w, const float* weight, const float* bias, int cout,
+                    int ksize, int act, float act_param, float* out, float* stats, void* workspace,
+                    size_t workspace_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (ksize != 1 && ksize != 3 && ksize != 7) return fail(RLN_ERR_UNSUPPORTED, "kernel size %d (1, 3, 7 are built)", ksize);
+  IgemmParams p;
+  memset(&p, 0, sizeof(p));
+  const size_t plane = (size_t)h * w;
+  p.in = x;
+  p.in_ns = (long long)cin * plane;
+  p.in_cs = (int)plane;
+  p.Hin = h;
+  p.Win = w;
+  p.K = cin;
+  p.w = weight;
+  p.w_js = (long long)cin * ksize * ksize;
+  p.w_ks = ksize * ksize;
+  p.tapmode = TM_ID;
+  p.J = cout;
+  p.GH = h;
+  p.GW = w;
+  p.ncls = 1;
+  p.out = out;
+  p.out_ns = (long long)cout * plane;
+  p.out_cs = (int)plane;
+  p.Hout = h;
+  p.Wout = w;
+  p.bias = bias;
+  p.act = act;
+  p.act_param = act_param;
+  const IgemmKind kind = ksize == 7 ? IG_CONV7_RAW : (ksize == 3 ? IG_CONV3_RAW : IG_CONV1_RAW);
+  const int tile = igemm_pick_tile(h, w);
+  int th, tw;
+  igemm_tile_dims(kind, tile, &th, &tw);
+  p.tiles_y = (h + th - 1) / th;
+  p.tiles_x = (w + tw - 1) / tw;
+  p.out_vec = ((w % 4) == 0 && aligned16(out)) ? 1 : 0;
+  const long long nblk = igemm_stat_blocks(p, n);
+  if (stats) {
+    if (!workspace || workspace_bytes < (size_t)nblk * cout * 2 * sizeof(float))
+      return fail(RLN_ERR_WORKSPACE, "stats need %lld bytes of workspace", nblk * cout * 2 * (long long)sizeof(float));
+    p.stat_partial = (float*)workspace;
+  }
+  RLN_TRY(igemm_launch(kind, tile, p, n, s));
+  if (stats) RLN_TRY(reduce_rows(p.stat_partial, nblk, (long long)cout * 2, stats, s));
+  return 0;
+}
+
+int rln_op_bn_affine(const float* sums, int c, double count, int training, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float momentum, float eps, float* a, float* b,
+                     void* stream) {
+  if (!training && (!running_mean || !running_var)) return fail(RLN_ERR_ARG, "eval mode needs running statistics");
+  RLN_TRY(bn_affine_from_sums(sums, c, count, training, gamma, beta, running_mean, running_var, momentum, eps, a, b,
+                              (hipStream_t)stream));
+  return 0;
+}
+
+int rln_op_bn_drop_maxpool(const float* x, int n, int c, int h, int w, const float* a, const float* b,
+                           const float* mask, int k, float* out, void* stream) {
+  if (k < 1 || (k & 1) == 0) return fail(RLN_ERR_ARG, "odd pooling kernel expected");
+  RLN_TRY(bn_drop_maxpool(x, n, c, h, w, a, b, mask, k, out, (hipStream_t)stream));
+  return 0;
+}
+
+int rln_op_bn_drop_upsample2(const float* x, int n, int c, int h, int w, const float* a, const float* b,
+                             const float* mask, float* out, void* stream) {
+  RLN_TRY(bn_drop_upsample2(x, n, c, h, w, a, b, mask, out, (hipStream_t)stream));
+  return 0;
+}
+
+int rln_op_softmax_channels(const float* x, int n, int c, int hw, float* out, void* stream) {
+  RLN_TRY(softmax_channels(x, n, c, hw, out, (hipStream_t)stream));
+  return 0;
+}
+
+int rln_op_dropout_mask(float* dst, int64_t count, float keep, uint64_t seed, void* stream) {
+  RLN_TRY(dropout_scales(dst, count, keep, (unsigned long long)seed, (hipStream_t)stream));
+  return 0;
+}
+
 int rln_op_classifier(const float* feat, int n, int c, int hw, const float* w, const float* b, int ncls, float T,
                       float* out, int use_softmax, void* stream) {
   HeadParams hp;

@@ -98,6 +98,19 @@ int head_backward_data(const HeadBwdParams& p, int N, long long* bias_rows, hipS
 // dW partial [N][ncls*C]
 int head_backward_weight(const HeadParams& h, int N, const float* glin, float* partial, hipStream_t s);
 
+// ---- EncDecNet pieces (models/EncDecNet.py:29-37,68-69,97,100-112) ----------------------------------------
+// a,b from per-channel (sum, sumsq) of the activated conv output (train) or running stats (eval); updates running stats
+int bn_affine_from_sums(const float* sums, int C, double count, int training, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, float momentum, float eps, float* a, float* b,
+                        hipStream_t s);
+// y = mask * (a[c]*x + b[c]); then MaxPool2d(k, stride 2, padding k/2)
+int bn_drop_maxpool(const float* x, int N, int C, int H, int W, const float* a, const float* b, const float* mask,
+                    int k, float* out, hipStream_t s);
+// y = mask * (a[c]*x + b[c]); then UpsamplingBilinear2d(scale_factor=2) (align_corners=True)
+int bn_drop_upsample2(const float* x, int N, int C, int H, int W, const float* a, const float* b, const float* mask,
+                      float* out, hipStream_t s);
+int softmax_channels(const float* x, int N, int C, int HW, float* out, hipStream_t s);
+
 // ---- misc ----------------------------------------------------------------------------------
 int adamw(float* p, const float* g, float* m, float* v, long long count, float lr, float b1, float b2, float eps,
           float wd, int step, float grad_scale, hipStream_t s);

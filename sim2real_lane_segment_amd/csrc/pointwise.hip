@@ -665,6 +665,132 @@ int head_backward_weight(const HeadParams& p, int N, const float* glin, float* p
   RLN_LAUNCH_CHECK();
 }
 
+// =============================================================================================
+// EncDecNet pieces
+// =============================================================================================
+
+__global__ __launch_bounds__(256) void bn_affine_from_sums_k(const float* __restrict__ sums, int C, double count,
+                                                             int training, const float* gamma, const float* beta,
+                                                             float* running_mean, float* running_var, float momentum,
+                                                             float eps, float* a, float* b) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float g = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+  if (training) {
+    const double m = (double)sums[2 * c] / count;
+    double v = (double)sums[2 * c + 1] / count - m * m;
+    if (v < 0.0) v = 0.0;
+    const float is = 1.0f / sqrtf((float)v + eps);
+    a[c] = g * is;
+    b[c] = be - (float)m * g * is;
+    if (running_mean != nullptr) {
+      const double unb = count > 1.0 ? count / (count - 1.0) : 1.0;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(v * unb);
+    }
+  } else {
+    const float is = 1.0f / sqrtf(running_var[c] + eps);
+    a[c] = g * is;
+    b[c] = be - running_mean[c] * g * is;
+  }
+}
+
+int bn_affine_from_sums(const float* sums, int C, double count, int training, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, float momentum, float eps, float* a, float* b,
+                        hipStream_t s) {
+  hipLaunchKernelGGL(bn_affine_from_sums_k, dim3((C + 255) / 256), dim3(256), 0, s, sums, C, count, training, gamma,
+                     beta, running_mean, running_var, momentum, eps, a, b);
+  RLN_LAUNCH_CHECK();
+}
+
+__global__ __launch_bounds__(256) void bn_drop_maxpool_k(const float* __restrict__ x, int C, int H, int W,
+                                                         const float* __restrict__ a, const float* __restrict__ b,
+                                                         const float* __restrict__ mask, int k, int Ho, int Wo,
+                                                         float* out) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= Ho * Wo) return;
+  const int oy = o / Wo, ox = o - oy * Wo;
+  const float av = a ? a[c] : 1.f, bv = b ? b[c] : 0.f;
+  const long long base = ((long long)n * C + c) * H * W;
+  const int pad = k / 2;
+  float best = -INFINITY;
+  for (int dy = 0; dy < k; ++dy) {
+    const int iy = 2 * oy - pad + dy;
+    if (iy < 0 || iy >= H) continue;
+    for (int dx = 0; dx < k; ++dx) {
+      const int ix = 2 * ox - pad + dx;
+      if (ix < 0 || ix >= W) continue;
+      const long long idx = base + (long long)iy * W + ix;
+      float v = fmaf(av, x[idx], bv);
+      if (mask) v *= mask[idx];
+      best = fmaxf(best, v);
+    }
+  }
+  out[((long long)n * C + c) * Ho * Wo + o] = best;
+}
+
+int bn_drop_maxpool(const float* x, int N, int C, int H, int W, const float* a, const float* b, const float* mask,
+                    int k, float* out, hipStream_t s) {
+  const int Ho = (H + 2 * (k / 2) - k) / 2 + 1, Wo = (W + 2 * (k / 2) - k) / 2 + 1;
+  hipLaunchKernelGGL(bn_drop_maxpool_k, dim3((Ho * Wo + 255) / 256, C, N), dim3(256), 0, s, x, C, H, W, a, b, mask, k,
+                     Ho, Wo, out);
+  RLN_LAUNCH_CHECK();
+}
+
+__global__ __launch_bounds__(256) void bn_drop_upsample2_k(const float* __restrict__ x, int C, int H, int W,
+                                                           const float* __restrict__ a, const float* __restrict__ b,
+                                                           const float* __restrict__ mask, float* out) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int Ho = 2 * H, Wo = 2 * W;
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= Ho * Wo) return;
+  const int oy = o / Wo, ox = o - oy * Wo;
+  const float av = a ? a[c] : 1.f, bv = b ? b[c] : 0.f;
+  const long long base = ((long long)n * C + c) * H * W;
+  // align_corners=True: src = dst * (in - 1) / (out - 1)
+  const float sy = Ho > 1 ? (float)oy * (float)(H - 1) / (float)(Ho - 1) : 0.f;
+  const float sx = Wo > 1 ? (float)ox * (float)(W - 1) / (float)(Wo - 1) : 0.f;
+  const int y0 = min((int)sy, H - 1), x0 = min((int)sx, W - 1);
+  const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+  const float fy = sy - (float)y0, fx = sx - (float)x0;
+  auto val = [&](int yy, int xx) {
+    const long long idx = base + (long long)yy * W + xx;
+    float v = fmaf(av, x[idx], bv);
+    if (mask) v *= mask[idx];
+    return v;
+  };
+  const float v00 = val(y0, x0), v01 = val(y0, x1), v10 = val(y1, x0), v11 = val(y1, x1);
+  const float top = v00 + (v01 - v00) * fx, bot = v10 + (v11 - v10) * fx;
+  out[((long long)n * C + c) * Ho * Wo + o] = top + (bot - top) * fy;
+}
+
+int bn_drop_upsample2(const float* x, int N, int C, int H, int W, const float* a, const float* b, const float* mask,
+                      float* out, hipStream_t s) {
+  hipLaunchKernelGGL(bn_drop_upsample2_k, dim3((4 * H * W + 255) / 256, C, N), dim3(256), 0, s, x, C, H, W, a, b, mask,
+                     out);
+  RLN_LAUNCH_CHECK();
+}
+
+__global__ __launch_bounds__(256) void softmax_channels_k(const float* __restrict__ x, int C, long long HW, float* out) {
+  const int n = blockIdx.y;
+  const long long px = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (px >= HW) return;
+  const float* xp = x + (long long)n * C * HW + px;
+  float m = xp[0];
+  for (int c = 1; c < C; ++c) m = fmaxf(m, xp[(long long)c * HW]);
+  float sum = 0.f;
+  for (int c = 0; c < C; ++c) sum += expf(xp[(long long)c * HW] - m);
+  const float inv = 1.f / sum;
+  float* op = out + (long long)n * C * HW + px;
+  for (int c = 0; c < C; ++c) op[(long long)c * HW] = expf(xp[(long long)c * HW] - m) * inv;
+}
+
+int softmax_channels(const float* x, int N, int C, int HW, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(softmax_channels_k, dim3((HW + 255) / 256, N), dim3(256), 0, s, x, C, (long long)HW, out);
+  RLN_LAUNCH_CHECK();
+}
+
 // adentropy forward
 template <int NC>
 __global__ __launch_bounds__(256) void entropy_k(const float* __restrict__ probs, int ncls, long long HW, long long npix,

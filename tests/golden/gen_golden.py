@@ -284,6 +284,55 @@ def gen_mme(name, cfg, n, h, w, seed):
     print(name, "loss0", float(loss0))
 
 
+def gen_encdec(name, n_feat, n_levels, k, n_lin, n, h, w, seed):
+    """The reference's legacy EncDecNet (models/EncDecNet.py): eval forward and train-mode forward with injected
+    Dropout masks; default-initialised weights are stored in the fixture (small nets)."""
+    from models.EncDecNet import EncDecNet
+    from oracle import encdecnet_oracle as E
+    torch.manual_seed(seed)
+    net = EncDecNet(n_feat, n_levels, k, n_lin)
+    with torch.no_grad():  # perturb BN so that the affine part and running stats are exercised
+        g = torch.Generator().manual_seed(seed + 1)
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.copy_(0.75 + 0.5 * torch.rand(m.weight.shape, generator=g))
+                m.bias.copy_(0.2 * (torch.rand(m.bias.shape, generator=g) - 0.5))
+                m.running_mean.copy_(0.1 * (torch.rand(m.bias.shape, generator=g) - 0.5))
+                m.running_var.copy_(0.75 + 0.5 * torch.rand(m.bias.shape, generator=g))
+    out = dict(n_feat=n_feat, n_levels=n_levels, k=k, n_lin=n_lin, n=n, h=h, w=w, seed=seed)
+    for key, v in net.state_dict().items():
+        out["state/" + key] = v.numpy().copy()
+    x, _ = synth_batch(n, h, w, 2, seed + 2)
+    net.eval()
+    with torch.no_grad():
+        out["eval_out"] = net(x).numpy()
+    masks = E.make_masks(E.mask_shapes(n, h, w, n_feat, n_levels, k), 0.3, seed + 3)
+    state = {"i": 0}
+    orig = torch.nn.Dropout.forward
+
+    def fwd(mod, t):
+        if not mod.training:
+            return t
+        m = masks[state["i"]]
+        state["i"] += 1
+        assert m.shape == t.shape
+        return t * m
+
+    torch.nn.Dropout.forward = fwd
+    try:
+        net.train()
+        with torch.no_grad():
+            out["train_out"] = net(x).numpy()
+        assert state["i"] == len(masks)
+    finally:
+        torch.nn.Dropout.forward = orig
+    for key, v in net.state_dict().items():
+        if "running" in key:
+            out["buf1/" + key] = v.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "ok", out["eval_out"].shape)
+
+
 def gen_misc(name):
     """Third-party arithmetic at the reference's call sites: AdamW(lr,weight_decay) 3 steps,
     CosineAnnealingLR(25, eta_min=lr/lrRatio) table, getClassWeight incl. an absent class."""
@@ -320,7 +369,7 @@ def main():
     _install_lightning_stub()
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["misc", "mme", "tiny", "tiny_odd", "g16", "g16_absent", "fcd67_eval", "fcd67_eval480",
+    which = sys.argv[1:] or ["misc", "mme", "encdec", "tiny", "tiny_odd", "g16", "g16_absent", "fcd67_eval", "fcd67_eval480",
                              "fcd67_train"]
     tiny = O.NetConfig(down_blocks=(2, 2), up_blocks=(2, 2), bottleneck_layers=2, growth_rate=4,
                        out_chans_first_conv=8, n_classes=4)
@@ -328,6 +377,10 @@ def main():
                       out_chans_first_conv=48, n_classes=4)
     if "misc" in which:
         gen_misc("misc")
+    if "encdec" in which:
+        gen_encdec("encdec_k3_relu_24x40", 8, 2, 3, "relu", 2, 24, 40, 900)
+        gen_encdec("encdec_k7_leaky_40x56", 8, 3, 7, "leakyRelu", 2, 40, 56, 910)
+        gen_encdec("encdec_k3_prelu_30x34", 6, 2, 3, "prelu", 1, 30, 34, 920)
     if "mme" in which:
         gen_mme("mme_tiny_40x56", tiny, 2, 40, 56, 800)
     if "tiny" in which:
