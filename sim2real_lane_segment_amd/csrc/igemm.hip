@@ -42,7 +42,9 @@ struct IgCfg {
   static constexpr int POOL_FLOATS = (EPI == EPI_POOL) ? 16 * OLS : 0;
   static constexpr int MAIN_FLOATS = cmax(IN_FLOATS + W_FLOATS, POOL_FLOATS);
   static constexpr int RED_FLOATS = 4 * NT * 16 * 2;
-  static constexpr int LDS_BYTES = (MAIN_FLOATS + RED_FLOATS) * 4;
+  static constexpr int AB_MAX = 1024;  // V4 + BN: per-channel (a, b) table of the whole layer lives in LDS
+  static constexpr int AB_FLOATS = (V4 && PRO == PRO_BNRELU) ? 2 * AB_MAX : 0;
+  static constexpr int LDS_BYTES = (MAIN_FLOATS + RED_FLOATS + AB_FLOATS) * 4;
   static constexpr int MPW = TH * TW / 64;
   __host__ __device__ static constexpr int slot_off(int s) {
     return S2D ? ((((s / 3) & 1) * 2 + ((s % 3) & 1)) * PLANE + ((s / 3) >> 1) * PITCH + ((s % 3) >> 1))
@@ -77,7 +79,8 @@ __device__ __forceinline__ void igemm_compute(const float* __restrict__ zbase, c
 }
 
 template <int KS, int NT, int PRO, int EPI, int TH, int TW, bool CLS, bool V4>
-__global__ __launch_bounds__(256, ((NT == 1 && TH * TW <= 256) ? 4 : 2)) void igemm_k(const IgemmParams p) {
+__global__ __launch_bounds__(256, ((NT == 1 && TH * TW <= 256) ? 4 : ((NT == 1 && TH * TW <= 320) ? 3 : 2)))
+    void igemm_k(const IgemmParams p) {
   using C = IgCfg<KS, NT, PRO, EPI, TH, TW, V4>;
   static_assert(!V4 || (PRO != PRO_S2D && C::CHS % 4 == 0 && C::PITCH % 4 == 0), "V4 needs 16-byte aligned LDS rows");
   constexpr int MPW = C::MPW;
@@ -86,9 +89,16 @@ __global__ __launch_bounds__(256, ((NT == 1 && TH * TW <= 256) ? 4 : 2)) void ig
   float* zl = smem;
   float* wl = smem + C::IN_FLOATS;
   float* red = smem + C::MAIN_FLOATS;
+  float* abl = smem + C::MAIN_FLOATS + C::RED_FLOATS;  // [2][AB_MAX] (V4 + BN only)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6, lj = lane & 15, lk = lane >> 4;
+  if constexpr (C::AB_FLOATS > 0) {  // read by the commit phases; the first __syncthreads orders it
+    for (int c = tid; c < p.K; c += 256) {
+      abl[c] = p.pa[c];
+      abl[C::AB_MAX + c] = p.pb[c];
+    }
+  }
   int bx = blockIdx.x;
   const int tiles = p.tiles_x * p.tiles_y;
   int cls = 0;
@@ -275,7 +285,7 @@ __global__ __launch_bounds__(256, ((NT == 1 && TH * TW <= 256) ? 4 : 2)) void ig
           const bool ok = ((qmeta[i] >> 28) & 1) && c <= kmax;
           float4 v = rq[i];
           if constexpr (PRO == PRO_BNRELU) {
-            const float a = p.pa[min(c, kmax)], b = p.pb[min(c, kmax)];
+            const float a = abl[min(c, kmax)], b = abl[C::AB_MAX + min(c, kmax)];
             v.x = fmaxf(fmaf(a, v.x, b), 0.f);
             v.y = fmaxf(fmaf(a, v.y, b), 0.f);
             v.z = fmaxf(fmaf(a, v.z, b), 0.f);
@@ -346,6 +356,7 @@ __global__ __launch_bounds__(256, ((NT == 1 && TH * TW <= 256) ? 4 : 2)) void ig
     ch_end = min(nchunk, ch_begin + per);
   }
   if (!(dbg & 1) && ch_begin < ch_end) issue(ch_begin);
+  if constexpr (C::AB_FLOATS > 0) __syncthreads();  // a/b table visible before the first commit
   if (stamps) {
     t_last = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -578,6 +589,7 @@ __global__ __launch_bounds__(256, ((NT == 1 && TH * TW <= 256) ? 4 : 2)) void ig
 template <int KS, int NT, int PRO, int EPI, int TH, int TW, bool CLS, bool V4>
 static int launch_v(const IgemmParams& p, int N, hipStream_t stream) {
   using C = IgCfg<KS, NT, PRO, EPI, TH, TW, V4>;
+  if (C::AB_FLOATS > 0 && p.K > C::AB_MAX) return -4;
   static bool attr_done = false;
   auto kern = igemm_k<KS, NT, PRO, EPI, TH, TW, CLS, V4>;
   if ((p.ncls > 1) != CLS) return -1;
@@ -642,6 +654,9 @@ void igemm_tile_dims(IgemmKind kind, int tile, int* th, int* tw) {
   } else if (tile == 3) {
     *th = 8;
     *tw = 80;
+  } else if (tile == 4) {  // half-width strips: 3 blocks per CU
+    *th = 4;
+    *tw = 80;
   } else if (tile == 0) {
     *th = 8;
     *tw = 32;
@@ -654,7 +669,11 @@ void igemm_tile_dims(IgemmKind kind, int tile, int* th, int* tw) {
 // strip tiles need the 16-byte staging path: W % 4 == 0 and aligned planes (checked by the caller)
 int igemm_pick_strip_tile(int gw) {
   if (getenv("RLN_NO_STRIP")) return -1;
-  return gw == 160 ? 2 : (gw == 80 ? 3 : -1);
+  static const int mode = getenv("RLN_STRIP_MODE") ? atoi(getenv("RLN_STRIP_MODE")) : 0;
+  if (mode == 1) return (gw == 160 || gw == 80) ? 4 : -1;  // experiment: 4x80 everywhere
+  if (mode == 2) return gw == 160 ? 4 : (gw == 80 ? 3 : -1);
+  if (mode == 3) return gw == 160 ? 2 : (gw == 80 ? 3 : -1);
+  return gw == 160 ? 4 : (gw == 80 ? 3 : -1);  // default: 4x80 half strips on 160-wide levels (3 blocks/CU), 8x80 on 80-wide
 }
 
 int igemm_pick_tile(int gh, int gw) {
@@ -669,6 +688,7 @@ int igemm_launch(IgemmKind kind, int tile, const IgemmParams& p, int N, hipStrea
     case IG_CONV3_BN:
       if (tile == 2) return launch_v<3, 1, PRO_BNRELU, EPI_STORE, 4, 160, false, true>(p, N, stream);
       if (tile == 3) return launch_v<3, 1, PRO_BNRELU, EPI_STORE, 8, 80, false, true>(p, N, stream);
+      if (tile == 4) return launch_v<3, 1, PRO_BNRELU, EPI_STORE, 4, 80, false, true>(p, N, stream);
       return tile == 0 ? launch_t<3, 1, PRO_BNRELU, EPI_STORE, 8, 32>(p, N, stream)
                        : launch_t<3, 1, PRO_BNRELU, EPI_STORE, 16, 16>(p, N, stream);
     case IG_CONV3_RAW:

@@ -2,7 +2,10 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 constexpr int H = 120, W = 160, CT = 288, N = 64, TH = 8, TW = 32;
-constexpr long long PLANE = (long long)H * W;
+#ifndef PAD
+#define PAD 0
+#endif
+constexpr long long PLANE = (long long)H * W + PAD;
 
 // A: dword loads, (TH+2)x(TW+2) tile positions, 16 channels per chunk (scalar staging pattern)
 template <bool BAR>
