@@ -34,4 +34,15 @@ constexpr int round_mod32(int x, int r) {  // smallest y >= x with y % 32 == r
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs (linear ids b and b+8 share an L2), so
+// neighbouring tiles of one sample would each pull their shared halo rows into a different L2.  This maps the
+// dispatch-order id to a logical id such that every XCD walks ONE contiguous range of the logical order
+// (bijective for any grid size).  Placement is a speed matter only; results never depend on it.
+__device__ inline unsigned xcd_logical_block(unsigned lin, unsigned total) {
+  const unsigned xcd = lin & 7u, slot = lin >> 3;
+  const unsigned q = total >> 3, r = total & 7u;
+  const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + slot;
+}
+
 }  // namespace rln

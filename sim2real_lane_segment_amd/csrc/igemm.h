@@ -51,7 +51,7 @@ struct IgemmParams {
   float act_param;
   int ksplit;          // >1: input-channel chunks split over blockIdx.y; raw partial sums go to out + split*split_stride
   long long split_stride;
-  int dbg;             // timing ablations only (RLN_DBG): 1 skip global loads, 2 skip LDS commit, 4 skip MFMA, 16 stamps
+  int dbg;             // timing ablations only (RLN_DBG): 1 skip global loads, 2 skip LDS commit, 4 skip MFMA, 16 stamps, 32 no XCD remap
   unsigned long long* dbg_out;  // [8] phase cycle sums (diagnostic build path only)
 };
 unsigned long long* igemm_debug_buffer();  // device buffer of 8 counters (allocated on first use)
@@ -100,6 +100,7 @@ struct WgradParams {
   float* partial;         // [nchunks][wsize]
   long long wsize;
   long long m_stride, n_stride;  // output index = m*m_stride + n*n_stride + tap
+  int no_xcd;             // timing ablation only (RLN_DBG=32): keep dispatch order
 };
 enum WgradKind {
   WG_DENSE3 = 0,  // M=U (dY 16ch), N=V (z = relu(a*S+b)), 9 taps

@@ -99,7 +99,18 @@ __global__ __launch_bounds__(256, ((NT == 1 && TH * TW <= 256) ? 4 : ((NT == 1 &
       abl[C::AB_MAX + c] = p.pb[c];
     }
   }
-  int bx = blockIdx.x;
+  // logical (x, y, sample) block coordinates: dispatch order remapped so that one XCD walks neighbouring tiles
+  unsigned lx = blockIdx.x, ly = blockIdx.y, lz = blockIdx.z;
+  if (!(p.dbg & 32)) {
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    unsigned l = xcd_logical_block(lin, gridDim.x * gridDim.y * gridDim.z);
+    lz = l / (gridDim.x * gridDim.y);
+    l -= lz * (gridDim.x * gridDim.y);
+    ly = l / gridDim.x;
+    lx = l - ly * gridDim.x;
+  }
+  const int bx0 = (int)lx;
+  int bx = bx0;
   const int tiles = p.tiles_x * p.tiles_y;
   int cls = 0;
   if constexpr (CLS) {
@@ -108,12 +119,12 @@ __global__ __launch_bounds__(256, ((NT == 1 && TH * TW <= 256) ? 4 : ((NT == 1 &
   }
   const int tile_y = bx / p.tiles_x, tile_x = bx - tile_y * p.tiles_x;
   const int gy0 = tile_y * TH, gx0 = tile_x * TW;
-  const int n = blockIdx.z;
-  int ky = 0, jy = blockIdx.y;
+  const int n = (int)lz;
+  int ky = 0, jy = (int)ly;
   if (p.ksplit > 1) {
     const int jgroups = (p.J + NT * 16 - 1) / (NT * 16);
-    ky = blockIdx.y / jgroups;
-    jy = blockIdx.y - ky * jgroups;
+    ky = (int)ly / jgroups;
+    jy = (int)ly - ky * jgroups;
   }
   const int jbase = jy * (NT * 16);
   const int py = cls >> 1, px = cls & 1;
@@ -396,7 +407,7 @@ __global__ __launch_bounds__(256, ((NT == 1 && TH * TW <= 256) ? 4 : ((NT == 1 &
     atomicAdd(&p.dbg_out[5], (unsigned long long)nchunk);
   }
 
-  const long long blk_lin = (long long)n * gridDim.x + blockIdx.x;
+  const long long blk_lin = (long long)n * gridDim.x + bx0;
 
   if constexpr (EPI == EPI_STORE || EPI == EPI_DGRAD) {
     constexpr int S_ = CLS ? 2 : 1;
@@ -730,7 +741,10 @@ int igemm_launch(IgemmKind kind, int tile, const IgemmParams& p, int N, hipStrea
 // and the BatchNorm-backward partial sums leave the block per wave (4 partial rows per block).
 // =============================================================================================
 
-template <int TH, int TW>
+// VEC: rows are 16-byte aligned and W % 4 == 0 (host-checked), so every 4-pixel group is all-in or all-out and the
+// S / G traffic moves as one 16-byte access per lane.  A compile-time switch: as a run-time branch the compiler
+// folds both forms into the scalar one (32 dword loads per lane and step instead of 8 dwordx4).
+template <int TH, int TW, bool VEC>
 __global__ __launch_bounds__(256, 3) void dgrad_loop_k(const IgemmParams p) {
   using C = IgCfg<3, 1, PRO_RAW, EPI_DGRAD, TH, TW>;
   constexpr int MPW = C::MPW;
@@ -815,7 +829,7 @@ __global__ __launch_bounds__(256, 3) void dgrad_loop_k(const IgemmParams p) {
     vmask |= bits << (4 * m);
     pixoff[m] = (bits & 1u) ? gy * p.GW + gx : 0;  // clamped to a valid pixel when the whole group is outside
   }
-  const bool vec = p.out_vec != 0;  // host: rows 16-byte aligned and W % 4 == 0 -> groups are all-in or all-out
+  constexpr bool vec = VEC;
   const float* Sn = p.S + (long long)n * p.s_ns;
   float* Gn = p.out + (long long)n * p.out_ns;
   const float* zbase = zl + lk * C::CHS + ((wave * MPW * 16) / TW) * C::PITCH + lj;
@@ -831,6 +845,26 @@ __global__ __launch_bounds__(256, 3) void dgrad_loop_k(const IgemmParams p) {
     commit_w(ct_begin, wl0 + (ct_begin & 1) * C::W_FLOATS);
   }
   __syncthreads();
+#ifdef RLN_DIAG
+  const bool stamps = (p.dbg & 16) != 0;
+#else
+  constexpr bool stamps = false;
+#endif
+  unsigned long long t_pre = 0, t_mfma = 0, t_wait = 0, t_epi = 0, t_tail = 0, t_last = 0;
+  auto stamp = [&](unsigned long long& acc) {
+    if (stamps) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      acc += t - t_last;
+      t_last = t;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if (stamps) {
+    t_last = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+  }
   for (int ct = ct_begin; ct < ct_end; ++ct) {
     float* wcur = wl0 + (ct & 1) * C::W_FLOATS;
     float* wnext = wl0 + ((ct + 1) & 1) * C::W_FLOATS;
@@ -843,7 +877,15 @@ __global__ __launch_bounds__(256, 3) void dgrad_loop_k(const IgemmParams p) {
     float sv[MPW][4], gv[MPW][4];
     const float* Sc = Sn + (long long)jc * p.out_cs;
     float* Gc = Gn + (long long)jc * p.out_cs;
-    if (vec) {
+#ifdef RLN_DIAG
+    if (p.dbg & 1) {  // timing ablation: no S/G reads
+#pragma unroll
+      for (int m = 0; m < MPW; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sv[m][r] = gv[m][r] = 1.f;
+    } else
+#endif
+    if constexpr (vec) {
 #pragma unroll
       for (int m = 0; m < MPW; ++m) {
         const float4 t4 = *reinterpret_cast<const float4*>(Sc + pixoff[m]);
@@ -866,7 +908,16 @@ __global__ __launch_bounds__(256, 3) void dgrad_loop_k(const IgemmParams p) {
     f32x4 acc[MPW][1];
 #pragma unroll
     for (int m = 0; m < MPW; ++m) acc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    stamp(t_pre);
+#ifdef RLN_DIAG
+    if (!(p.dbg & 4))
+#endif
     igemm_compute<C, 1, TW, 0x1FFull>(zbase, wcur + lane, acc);
+    stamp(t_mfma);
+    if (stamps) {  // diagnostic only: separate the wait for the prefetched operands from the epilogue proper
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+      stamp(t_wait);
+    }
 
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -882,7 +933,12 @@ __global__ __launch_bounds__(256, 3) void dgrad_loop_k(const IgemmParams p) {
         s2 += gyv * xh;
         ov[r] = fmaf(egam, gyv, accum ? gv[m][r] : 0.f);
       }
-      if (vec) {
+#ifdef RLN_DIAG
+      if (p.dbg & 2) {  // timing ablation: no G writes (keep the values live)
+        if (ov[0] + ov[1] + ov[2] + ov[3] == 1.2345e-30f) Gc[0] = ov[0];
+      } else
+#endif
+      if constexpr (vec) {
         if (jv && ((vmask >> (4 * m)) & 1u))
           *reinterpret_cast<float4*>(Gc + pixoff[m]) = make_float4(ov[0], ov[1], ov[2], ov[3]);
       } else {
@@ -891,6 +947,7 @@ __global__ __launch_bounds__(256, 3) void dgrad_loop_k(const IgemmParams p) {
           if (jv && ((vmask >> (4 * m + r)) & 1u)) Gc[pixoff[m] + r] = ov[r];
       }
     }
+    stamp(t_epi);
     s1 = group4_sum(s1);
     s2 = group4_sum(s2);
     if (lk == 0) {  // per-wave slot in LDS; summed over the 4 waves after the loop
@@ -899,6 +956,15 @@ __global__ __launch_bounds__(256, 3) void dgrad_loop_k(const IgemmParams p) {
     }
     if (ct + 1 < ct_end) commit_w(ct + 1, wnext);
     __syncthreads();
+    stamp(t_tail);
+  }
+  if (stamps && lane == 0 && p.dbg_out) {
+    atomicAdd(&p.dbg_out[0], t_pre);
+    atomicAdd(&p.dbg_out[1], t_mfma);
+    atomicAdd(&p.dbg_out[2], t_wait);
+    atomicAdd(&p.dbg_out[3], t_epi);
+    atomicAdd(&p.dbg_out[4], t_tail);
+    atomicAdd(&p.dbg_out[5], (unsigned long long)(ct_end - ct_begin));
   }
   if (p.stat_partial != nullptr) {
     const long long brow = (long long)n * gridDim.x + blockIdx.x;
@@ -915,12 +981,12 @@ __global__ __launch_bounds__(256, 3) void dgrad_loop_k(const IgemmParams p) {
   }
 }
 
-template <int TH, int TW>
+template <int TH, int TW, bool VEC>
 static int dgrad_loop_launch_t(const IgemmParams& p, int N, hipStream_t stream) {
   using C = IgCfg<3, 1, PRO_RAW, EPI_DGRAD, TH, TW>;
   const int LDS = (C::IN_FLOATS + 2 * C::W_FLOATS + 4 * (((p.J + 15) >> 4) * 16) * 2) * 4;
   static bool attr_done = false;
-  auto kern = dgrad_loop_k<TH, TW>;
+  auto kern = dgrad_loop_k<TH, TW, VEC>;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               96 * 1024);
@@ -938,6 +1004,15 @@ static int dgrad_loop_launch_t(const IgemmParams& p, int N, hipStream_t stream) 
   int split = 1;
   if (base_blocks < 512) split = (int)std::min<long long>((512 + base_blocks - 1) / base_blocks, (long long)nct);
   dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)split, (unsigned)N);
+  static const int dbg = getenv("RLN_DBG") ? atoi(getenv("RLN_DBG")) : 0;
+  if ((dbg & 64) && TH == 8 && p.GW >= 160) {  // diagnostic build: phase stamps / ablations of the level-0 launches
+    static const int abl = getenv("RLN_DG_ABL") ? atoi(getenv("RLN_DG_ABL")) : 0;
+    IgemmParams q = p;
+    q.dbg = 16 | abl;
+    q.dbg_out = igemm_debug_buffer();
+    hipLaunchKernelGGL(kern, grid, dim3(256), LDS, stream, q);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(kern, grid, dim3(256), LDS, stream, p);
   return (int)hipGetLastError();
 }
@@ -945,7 +1020,9 @@ static int dgrad_loop_launch_t(const IgemmParams& p, int N, hipStream_t stream) 
 // K (= dY channels) must be <= 16.  One stat-partial row per block.
 int dgrad_loop_launch(int tile, const IgemmParams& p, int N, hipStream_t stream) {
   if (p.K > 16 || p.ncls != 1) return -1;
-  return tile == 0 ? dgrad_loop_launch_t<8, 32>(p, N, stream) : dgrad_loop_launch_t<16, 16>(p, N, stream);
+  if (p.out_vec)
+    return tile == 0 ? dgrad_loop_launch_t<8, 32, true>(p, N, stream) : dgrad_loop_launch_t<16, 16, true>(p, N, stream);
+  return tile == 0 ? dgrad_loop_launch_t<8, 32, false>(p, N, stream) : dgrad_loop_launch_t<16, 16, false>(p, N, stream);
 }
 
 // =============================================================================================
@@ -988,9 +1065,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_k(const WgradParams p) {
   float* ul = smem + C::V_FLOATS;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6, lj = lane & 15, lk = lane >> 4;
-  const int chunk = blockIdx.x;
-  const int mbase = blockIdx.y * C::MCH;
-  const int nbase = blockIdx.z * C::NCH;
+  // XCD-aware order: neighbouring chunks (neighbouring tiles, shared halo rows) of one channel group on one XCD
+  unsigned lx = blockIdx.x, ly = blockIdx.y, lz = blockIdx.z;
+  if (!p.no_xcd) {
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    unsigned l = xcd_logical_block(lin, gridDim.x * gridDim.y * gridDim.z);
+    lz = l / (gridDim.x * gridDim.y);
+    l -= lz * (gridDim.x * gridDim.y);
+    ly = l / gridDim.x;
+    lx = l - ly * gridDim.x;
+  }
+  const int chunk = (int)lx;
+  const int mbase = (int)ly * C::MCH;
+  const int nbase = (int)lz * C::NCH;
   const int ubase = SHIFT_A ? nbase : mbase;
   const int vbase = SHIFT_A ? mbase : nbase;
 
@@ -1177,6 +1264,13 @@ static int wlaunch_t(const WgradParams& p, hipStream_t stream) {
   const int Mc = SHIFT_A ? p.Vc : p.Uc;
   const int Nc = SHIFT_A ? p.Uc : p.Vc;
   dim3 grid((unsigned)p.nchunks, (unsigned)((Mc + C::MCH - 1) / C::MCH), (unsigned)((Nc + 63) / 64));
+  static const int dbg = getenv("RLN_DBG") ? atoi(getenv("RLN_DBG")) : 0;
+  if (dbg & 32) {
+    WgradParams q = p;
+    q.no_xcd = 1;
+    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, stream, q);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, stream, p);
   return (int)hipGetLastError();
 }

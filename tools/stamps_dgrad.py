@@ -1,0 +1,22 @@
+"""Diagnostic: per-phase cycle shares of the level-0 dense data-gradient kernel (diag build, RLN_DBG=64)."""
+import ctypes, sys, torch
+sys.path.insert(0, ".")
+from sim2real_lane_segment_amd import _lib
+from sim2real_lane_segment_amd.trainingModules.SimpleTrain import SimpleTrainModule
+from sim2real_lane_segment_amd.synthetic import make_batch
+m = SimpleTrainModule(num_cls=4).cuda(); m.train(); eng = m._rln_sync()
+x, y = make_batch(64, device="cuda")
+L = _lib.lib(); buf = (ctypes.c_uint64 * 8)()
+for it in range(2):
+    probs, _ = eng.forward(x, training=True, with_backward=True)
+    eng.loss(probs, y, weighted=True)
+    torch.cuda.synchronize()
+    L.rln_debug_read_stamps(buf)   # clear forward-side counters
+    eng.backward()
+    torch.cuda.synchronize()
+    L.rln_debug_read_stamps(buf)
+tot = sum(buf[i] for i in range(5)) or 1
+names = ["pre (weights + S/G prefetch issue)", "mfma", "wait vmcnt(0)", "epilogue VALU + stores", "tail (reduce, commit_w, barrier)"]
+for i, n in enumerate(names):
+    print(f"{n:36s} {100.0 * buf[i] / tot:5.1f}%   {buf[i] / max(buf[5],1) / 4:9.0f} ticks per step per wave")
+print("steps", buf[5] // 4)
