@@ -101,6 +101,7 @@ struct WgradParams {
   long long wsize;
   long long m_stride, n_stride;  // output index = m*m_stride + n*n_stride + tap
   int no_xcd;             // timing ablation only (RLN_DBG=32): keep dispatch order
+  unsigned long long* dbg_out;  // diagnostic build only: phase cycle sums
 };
 enum WgradKind {
   WG_DENSE3 = 0,  // M=U (dY 16ch), N=V (z = relu(a*S+b)), 9 taps

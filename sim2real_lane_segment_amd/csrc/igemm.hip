@@ -1047,7 +1047,8 @@ struct WgCfg {
   static constexpr int UCH = SHIFT_A ? NCH : MCH;
   static constexpr int V_FLOATS = VCH * VST;
   static constexpr int U_FLOATS = UCH * UST;
-  static constexpr int LDS_BYTES = (V_FLOATS + U_FLOATS) * 4;
+  static constexpr int AB_FLOATS = (PRO == PRO_BNRELU) ? 2 * VCH : 0;
+  static constexpr int LDS_BYTES = (V_FLOATS + U_FLOATS + AB_FLOATS) * 4;
   __host__ __device__ static constexpr int slot_off(int s) {
     return S2D ? ((((s / 3) & 1) * 2 + ((s % 3) & 1)) * PLANE + ((s / 3) >> 1) * PITCH + ((s % 3) >> 1))
                : ((s / KS) * PITCH + (s % KS));
@@ -1126,17 +1127,31 @@ __global__ __launch_bounds__(256, 2) void wgrad_k(const WgradParams p) {
     }
   }
 
-  // Register-staged pipeline (see igemm_k): loads of item it+1 fly while item it is in the MFMA phase.
+  // BatchNorm scale/shift of this block's V channels: constant over the items, read from LDS in the commit phase
+  // (applying them in the issue phase would make every load wait for its data and serialise the prefetch).
+  float* abl = ul + C::U_FLOATS;  // [VCH][2]
+  if constexpr (PRO == PRO_BNRELU) {
+    for (int c = tid; c < C::VCH; c += 256) {
+      const int cg = min(vbase + c, p.Vc - 1);
+      abl[2 * c + 0] = p.pa[cg];
+      abl[2 * c + 1] = p.pb[cg];
+    }
+  }
+  // Register-staged pipeline (see igemm_k): loads of item it+1 fly while item it is in the MFMA phase.  The issue
+  // phase only issues (raw values + validity bits); the commit phase applies activation / masks and writes LDS.
+  unsigned okbits = 0;  // bit 0: U position valid, bit 1+k: V sub-pass k valid
   auto issue = [&](long long it) {
     const int n = (int)(it / tiles);
     const int t = (int)(it - (long long)n * tiles);
     const int tile_y = t / p.tiles_x, tile_x = t - tile_y * p.tiles_x;
     const int gy0 = tile_y * TH, gx0 = tile_x * TW;
-    // Unconditional loads from clamped (always valid) addresses + a select: straight-line code, no per-load
-    // branch.  Address = uniform channel base (SGPR pair, clamped) + ONE 32-bit per-thread offset.
+    unsigned bits = 0;
+    // Unconditional loads from clamped (always valid) addresses: straight-line code, no per-load branch.
+    // Address = uniform channel base (SGPR pair, clamped) + ONE 32-bit per-thread offset.
     {
       const int gy = gy0 + u_ty, gx = gx0 + u_tx;
       const bool ok = gy < p.GH && gx < p.GW;
+      bits |= ok ? 1u : 0u;
       const int usafe = min(u_sub, p.Uc - 1);
       const int uoff = usafe * p.u_cs + (ok ? gy * p.GW + gx : 0);
       const float* un = p.u + (long long)n * p.u_ns;
@@ -1144,8 +1159,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_k(const WgradParams p) {
 #pragma unroll
       for (int i = 0; i < NUP; ++i) {
         const float* chan = un + (long long)min(ubase + i * UG, cumax) * p.u_cs;
-        const float v = chan[uoff];
-        ru[i] = (ok && ubase + i * UG + u_sub < p.Uc) ? v : 0.f;
+        ru[i] = chan[uoff];
       }
     }
     const int oy = C::S2D ? 2 * gy0 : gy0, ox = C::S2D ? 2 * gx0 : gx0;
@@ -1156,39 +1170,70 @@ __global__ __launch_bounds__(256, 2) void wgrad_k(const WgradParams p) {
     for (int k = 0; k < VSUB; ++k) {
       const int iy = oy + v_dy[k], ix = ox + v_dx[k];
       const bool ok = v_pos[k] >= 0 && iy >= 0 && iy < p.Hv && ix >= 0 && ix < p.Wv;
+      bits |= (ok ? 1u : 0u) << (1 + k);
       const int voff = vsafe * p.v_cs + (ok ? iy * p.Wv + ix : 0);
 #pragma unroll
       for (int i = 0; i < C::VCH / VG; ++i) {
         const int cu = min(vbase + i * VG, cvmax);  // uniform
         const float* chan = vn + (long long)cu * p.v_cs;
-        float v = chan[voff];
-        if constexpr (PRO == PRO_BNRELU) {
-          const float* pa = p.pa + cu;
-          const float* pb = p.pb + cu;
-          v = fmaxf(fmaf(pa[vsafe], v, pb[vsafe]), 0.f);
-        }
-        rv[i * VSUB + k] = (ok && vbase + i * VG + v_sub < p.Vc) ? v : 0.f;
+        rv[i * VSUB + k] = chan[voff];
       }
     }
+    okbits = bits;
   };
   auto commit = [&]() {
+    const bool uok = okbits & 1u;
 #pragma unroll
-    for (int i = 0; i < NUP; ++i) ul[(i * UG + u_sub) * C::UST + u_q] = ru[i];
+    for (int i = 0; i < NUP; ++i)
+      ul[(i * UG + u_sub) * C::UST + u_q] = (uok && ubase + i * UG + u_sub < p.Uc) ? ru[i] : 0.f;
 #pragma unroll
     for (int k = 0; k < VSUB; ++k) {
       if (v_pos[k] >= 0) {
+        const bool vok = (okbits >> (1 + k)) & 1u;
 #pragma unroll
-        for (int i = 0; i < C::VCH / VG; ++i) vl[(i * VG + v_sub) * C::VST + v_pos[k]] = rv[i * VSUB + k];
+        for (int i = 0; i < C::VCH / VG; ++i) {
+          const int c = i * VG + v_sub;
+          float v = rv[i * VSUB + k];
+          if constexpr (PRO == PRO_BNRELU) {
+            const float2 ab = *reinterpret_cast<const float2*>(abl + 2 * c);
+            v = fmaxf(fmaf(ab.x, v, ab.y), 0.f);
+          }
+          vl[c * C::VST + v_pos[k]] = (vok && vbase + c < p.Vc) ? v : 0.f;
+        }
       }
     }
   };
 
+#ifdef RLN_DIAG
+  const bool stamps = p.dbg_out != nullptr;
+#else
+  constexpr bool stamps = false;
+#endif
+  unsigned long long t_bar1 = 0, t_commit = 0, t_bar2 = 0, t_issue = 0, t_mfma = 0, t_last = 0;
+  auto stamp = [&](unsigned long long& acc) {
+    if (stamps) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      acc += t - t_last;
+      t_last = t;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   if (it0 < it1) issue(it0);
+  if (stamps) {
+    t_last = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+  }
   for (long long it = it0; it < it1; ++it) {
     __syncthreads();  // every wave is done reading the previous item
+    stamp(t_bar1);
     commit();
+    stamp(t_commit);
     __syncthreads();
+    stamp(t_bar2);
     if (it + 1 < it1) issue(it + 1);
+    stamp(t_issue);
     // ---- MFMA over the tile's pixels, 4 consecutive x per k-step; straight-line, constexpr LDS offsets ----
     {
       const float* ubase = ul + lj * C::UST + lk;
@@ -1227,6 +1272,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_k(const WgradParams p) {
         }
       }
     }
+    stamp(t_mfma);
+  }
+  if (stamps && lane == 0) {
+    atomicAdd(&p.dbg_out[0], t_bar1);
+    atomicAdd(&p.dbg_out[1], t_commit);
+    atomicAdd(&p.dbg_out[2], t_bar2);
+    atomicAdd(&p.dbg_out[3], t_issue);
+    atomicAdd(&p.dbg_out[4], t_mfma);
+    atomicAdd(&p.dbg_out[5], (unsigned long long)(it1 - it0));
   }
 
   const int Mc = SHIFT_A ? p.Vc : p.Uc;
@@ -1265,9 +1319,11 @@ static int wlaunch_t(const WgradParams& p, hipStream_t stream) {
   const int Nc = SHIFT_A ? p.Uc : p.Vc;
   dim3 grid((unsigned)p.nchunks, (unsigned)((Mc + C::MCH - 1) / C::MCH), (unsigned)((Nc + 63) / 64));
   static const int dbg = getenv("RLN_DBG") ? atoi(getenv("RLN_DBG")) : 0;
-  if (dbg & 32) {
+  if (dbg & (32 | 128)) {
     WgradParams q = p;
-    q.no_xcd = 1;
+    if (dbg & 32) q.no_xcd = 1;
+    // diagnostic build: phase stamps of the level-0 dense launches (RLN_DBG=128)
+    if ((dbg & 128) && KS == 3 && PRO == PRO_BNRELU && p.GW >= 160) q.dbg_out = igemm_debug_buffer();
     hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, stream, q);
     return (int)hipGetLastError();
   }

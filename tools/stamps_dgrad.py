@@ -16,7 +16,7 @@ for it in range(2):
     torch.cuda.synchronize()
     L.rln_debug_read_stamps(buf)
 tot = sum(buf[i] for i in range(5)) or 1
-names = ["pre (weights + S/G prefetch issue)", "mfma", "wait vmcnt(0)", "epilogue VALU + stores", "tail (reduce, commit_w, barrier)"]
+names = sys.argv[1].split(",") if len(sys.argv) > 1 else ["pre (weights + S/G prefetch issue)", "mfma", "wait vmcnt(0)", "epilogue VALU + stores", "tail (reduce, commit_w, barrier)"]
 for i, n in enumerate(names):
-    print(f"{n:36s} {100.0 * buf[i] / tot:5.1f}%   {buf[i] / max(buf[5],1) / 4:9.0f} ticks per step per wave")
+    print(f"{n:36s} {100.0 * buf[i] / tot:5.1f}%   {buf[i] / max(buf[5],1) :9.0f} cycles per step per wave")
 print("steps", buf[5] // 4)
