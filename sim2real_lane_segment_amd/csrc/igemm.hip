@@ -920,9 +920,9 @@ __global__ __launch_bounds__(256, 3) void dgrad_loop_k(const IgemmParams p) {
     }
 
     float s1 = 0.f, s2 = 0.f;
+    float ov[MPW][4];
 #pragma unroll
     for (int m = 0; m < MPW; ++m) {
-      float ov[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const bool ok = jv && ((vmask >> (4 * m + r)) & 1u);
@@ -931,20 +931,30 @@ __global__ __launch_bounds__(256, 3) void dgrad_loop_k(const IgemmParams p) {
         const float xh = (sv[m][r] - emean) * einv;
         s1 += gyv;
         s2 += gyv * xh;
-        ov[r] = fmaf(egam, gyv, accum ? gv[m][r] : 0.f);
+        ov[m][r] = fmaf(egam, gyv, accum ? gv[m][r] : 0.f);
       }
+    }
+    // Two things the wait-count logic needs from the source (vmcnt counts loads and stores together, in order):
+    //  * every prefetched register is consumed on EVERY path -- with the arithmetic sunk into a predicated store
+    //    block, the skip path leaves loads "pending" and a vmcnt(0) lands at the top of the next step;
+    //  * all loads are consumed BEFORE the first store is issued -- a load consumed after a store waits for that
+    //    store's completion.
+#pragma unroll
+    for (int m = 0; m < MPW; ++m) asm volatile("" ::"v"(ov[m][0]), "v"(ov[m][1]), "v"(ov[m][2]), "v"(ov[m][3]) : "memory");
+#pragma unroll
+    for (int m = 0; m < MPW; ++m) {
 #ifdef RLN_DIAG
       if (p.dbg & 2) {  // timing ablation: no G writes (keep the values live)
-        if (ov[0] + ov[1] + ov[2] + ov[3] == 1.2345e-30f) Gc[0] = ov[0];
+        if (ov[m][0] + ov[m][1] + ov[m][2] + ov[m][3] == 1.2345e-30f) Gc[0] = ov[m][0];
       } else
 #endif
       if constexpr (vec) {
         if (jv && ((vmask >> (4 * m)) & 1u))
-          *reinterpret_cast<float4*>(Gc + pixoff[m]) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+          *reinterpret_cast<float4*>(Gc + pixoff[m]) = make_float4(ov[m][0], ov[m][1], ov[m][2], ov[m][3]);
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (jv && ((vmask >> (4 * m + r)) & 1u)) Gc[pixoff[m] + r] = ov[r];
+          if (jv && ((vmask >> (4 * m + r)) & 1u)) Gc[pixoff[m] + r] = ov[m][r];
       }
     }
     stamp(t_epi);
@@ -1131,10 +1141,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_k(const WgradParams p) {
   // (applying them in the issue phase would make every load wait for its data and serialise the prefetch).
   float* abl = ul + C::U_FLOATS;  // [VCH][2]
   if constexpr (PRO == PRO_BNRELU) {
-    for (int c = tid; c < C::VCH; c += 256) {
+    for (int c = tid; c < C::VCH; c += 256) {  // channels past Vc get (0, 0): relu(0 * v + 0) = 0, no select needed
+      const bool cv = vbase + c < p.Vc;
       const int cg = min(vbase + c, p.Vc - 1);
-      abl[2 * c + 0] = p.pa[cg];
-      abl[2 * c + 1] = p.pb[cg];
+      abl[2 * c + 0] = cv ? p.pa[cg] : 0.f;
+      abl[2 * c + 1] = cv ? p.pb[cg] : 0.f;
     }
   }
   // Register-staged pipeline (see igemm_k): loads of item it+1 fly while item it is in the MFMA phase.  The issue
@@ -1152,20 +1163,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_k(const WgradParams p) {
       const int gy = gy0 + u_ty, gx = gx0 + u_tx;
       const bool ok = gy < p.GH && gx < p.GW;
       bits |= ok ? 1u : 0u;
+      // one uniform 64-bit base per operand and sample; everything per channel is a 32-bit offset
+      const int cumax = max(p.Uc - UG, 0);
+      const int ub0 = min(ubase, cumax);
       const int usafe = min(u_sub, p.Uc - 1);
       const int uoff = usafe * p.u_cs + (ok ? gy * p.GW + gx : 0);
-      const float* un = p.u + (long long)n * p.u_ns;
-      const int cumax = max(p.Uc - UG, 0);
+      const float* un = p.u + (long long)n * p.u_ns + (long long)ub0 * p.u_cs;
 #pragma unroll
-      for (int i = 0; i < NUP; ++i) {
-        const float* chan = un + (long long)min(ubase + i * UG, cumax) * p.u_cs;
-        ru[i] = chan[uoff];
-      }
+      for (int i = 0; i < NUP; ++i) ru[i] = un[uoff + (min(ubase + i * UG, cumax) - ub0) * p.u_cs];
     }
     const int oy = C::S2D ? 2 * gy0 : gy0, ox = C::S2D ? 2 * gx0 : gx0;
-    const float* vn = p.v + (long long)n * p.v_ns;
-    const int vsafe = min(v_sub, p.Vc - 1);
     const int cvmax = max(p.Vc - VG, 0);
+    const int vb0 = min(vbase, cvmax);
+    const float* vn = p.v + (long long)n * p.v_ns + (long long)vb0 * p.v_cs;
+    const int vsafe = min(v_sub, p.Vc - 1);
 #pragma unroll
     for (int k = 0; k < VSUB; ++k) {
       const int iy = oy + v_dy[k], ix = ox + v_dx[k];
@@ -1173,11 +1184,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_k(const WgradParams p) {
       bits |= (ok ? 1u : 0u) << (1 + k);
       const int voff = vsafe * p.v_cs + (ok ? iy * p.Wv + ix : 0);
 #pragma unroll
-      for (int i = 0; i < C::VCH / VG; ++i) {
-        const int cu = min(vbase + i * VG, cvmax);  // uniform
-        const float* chan = vn + (long long)cu * p.v_cs;
-        rv[i * VSUB + k] = chan[voff];
-      }
+      for (int i = 0; i < C::VCH / VG; ++i)
+        rv[i * VSUB + k] = vn[voff + (min(vbase + i * VG, cvmax) - vb0) * p.v_cs];  // uniform 32-bit channel offset
     }
     okbits = bits;
   };
@@ -1189,16 +1197,29 @@ __global__ __launch_bounds__(256, 2) void wgrad_k(const WgradParams p) {
 #pragma unroll
     for (int k = 0; k < VSUB; ++k) {
       if (v_pos[k] >= 0) {
-        const bool vok = (okbits >> (1 + k)) & 1u;
+        const float vmul = ((okbits >> (1 + k)) & 1u) ? 1.f : 0.f;  // padding positions -> exact 0
+        constexpr int NI = C::VCH / VG;
+        if constexpr (PRO == PRO_BNRELU) {
+          constexpr int GRP = 8;  // table reads in groups: one LDS wait per 8 channels instead of one per channel
+          static_assert(NI % GRP == 0, "channel groups");
 #pragma unroll
-        for (int i = 0; i < C::VCH / VG; ++i) {
-          const int c = i * VG + v_sub;
-          float v = rv[i * VSUB + k];
-          if constexpr (PRO == PRO_BNRELU) {
-            const float2 ab = *reinterpret_cast<const float2*>(abl + 2 * c);
-            v = fmaxf(fmaf(ab.x, v, ab.y), 0.f);
+          for (int g = 0; g < NI; g += GRP) {
+            float2 ab[GRP];
+#pragma unroll
+            for (int j = 0; j < GRP; ++j) ab[j] = *reinterpret_cast<const float2*>(abl + 2 * ((g + j) * VG + v_sub));
+#pragma unroll
+            for (int j = 0; j < GRP; ++j) {
+              const int c = (g + j) * VG + v_sub;
+              const float z = fmaxf(fmaf(ab[j].x, rv[(g + j) * VSUB + k], ab[j].y), 0.f);
+              vl[c * C::VST + v_pos[k]] = z * vmul;
+            }
           }
-          vl[c * C::VST + v_pos[k]] = (vok && vbase + c < p.Vc) ? v : 0.f;
+        } else {
+#pragma unroll
+          for (int i = 0; i < NI; ++i) {
+            const int c = i * VG + v_sub;
+            vl[c * C::VST + v_pos[k]] = (vmul != 0.f && vbase + c < p.Vc) ? rv[i * VSUB + k] : 0.f;
+          }
         }
       }
     }
