@@ -100,7 +100,7 @@ struct WgradParams {
   float* partial;         // [nchunks][wsize]
   long long wsize;
   long long m_stride, n_stride;  // output index = m*m_stride + n*n_stride + tap
-  int no_xcd;             // timing ablation only (RLN_DBG=32): keep dispatch order
+  int xcd_remap;          // timing ablation only (RLN_DBG=256): XCD-aware chunk order
   unsigned long long* dbg_out;  // diagnostic build only: phase cycle sums
 };
 enum WgradKind {
