@@ -13,6 +13,7 @@
 #include "igemm.h"
 
 #include <algorithm>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 
@@ -1320,6 +1321,203 @@ __global__ __launch_bounds__(256, 2) void wgrad_k(const WgradParams p) {
       }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Dense-layer weight gradient with 16-byte staging (levels whose rows are 16-byte aligned and W % 4 == 0).
+// Same contraction and partial-slab contract as wgrad_k<3,1,PRO_BNRELU,false>, but the V image is aligned in x
+// (it starts 4 columns left of the tile and is TW+8 wide) so that global loads are dwordx4 (17 per thread and
+// item instead of 72 dword loads) and LDS commits are ds_write_b64.
+template <int TH, int TW>
+struct WgqCfg {
+  static constexpr int QW = TW / 4 + 2;       // quads per image row
+  static constexpr int ROWS = TH + 2;
+  static constexpr int PITCH = 4 * QW;
+  static constexpr int POS = ROWS * PITCH;
+  static constexpr int QPC = ROWS * QW;       // quads per channel
+  static constexpr int VST = round_mod32(POS, 2);
+  static constexpr int UST = round_mod32(TH * TW, 2);
+  static constexpr int NCH = 64, MCH = 16;
+  static constexpr int NQV = NCH * QPC / 256;
+  static constexpr int NQU = MCH * (TH * TW / 4) / 256;
+  static constexpr int V_FLOATS = NCH * VST;
+  static constexpr int U_FLOATS = MCH * UST;
+  static constexpr int LDS_BYTES = (V_FLOATS + U_FLOATS + 2 * NCH) * 4;
+  static_assert((NCH * QPC) % 256 == 0 && (MCH * TH * TW / 4) % 256 == 0, "whole passes");
+  static_assert(TH * TW == 128 && VST % 2 == 0 && UST % 2 == 0, "128-pixel tiles, 8-byte aligned LDS rows");
+  __host__ __device__ static constexpr int slot_off(int s) { return (s / 3) * PITCH + (s % 3) + 3; }
+};
+
+template <int TH, int TW>
+__global__ __launch_bounds__(256, 2) void wgrad_dense_q_k(const WgradParams p) {
+  using C = WgqCfg<TH, TW>;
+  extern __shared__ __align__(16) float smem[];
+  float* vl = smem;
+  float* ul = smem + C::V_FLOATS;
+  float* abl = ul + C::U_FLOATS;  // [NCH][2]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, lj = lane & 15, lk = lane >> 4;
+  const int chunk = blockIdx.x;
+  const int nbase = blockIdx.z * C::NCH;  // V (conv input) channels of this block; U = all 16 dY channels
+
+  for (int c = tid; c < C::NCH; c += 256) {  // channels past Vc get (0, 0): relu(0 * v + 0) = 0
+    const bool cv = nbase + c < p.Vc;
+    const int cg = min(nbase + c, p.Vc - 1);
+    abl[2 * c + 0] = cv ? p.pa[cg] : 0.f;
+    abl[2 * c + 1] = cv ? p.pb[cg] : 0.f;
+  }
+
+  // staging map: quad e = tid + 256 i  ->  (channel, image row, quad in row)
+  int vgo[C::NQV], vmeta[C::NQV];  // global offset relative to (sample, tile origin) ; lds | r << 20 | q << 24
+#pragma unroll
+  for (int i = 0; i < C::NQV; ++i) {
+    const int e = tid + 256 * i;
+    const int ch = e / C::QPC, rem = e - ch * C::QPC;
+    const int r = rem / C::QW, q = rem - r * C::QW;
+    const int cg = min(nbase + ch, p.Vc - 1) - min(nbase, p.Vc - 1);
+    vgo[i] = cg * p.v_cs + (r - 1) * p.Wv + 4 * q - 4;
+    vmeta[i] = (ch * C::VST + r * C::PITCH + 4 * q) | (r << 20) | (q << 24);
+  }
+  int ugo[C::NQU], ulo[C::NQU], uty[C::NQU], utx[C::NQU];
+#pragma unroll
+  for (int i = 0; i < C::NQU; ++i) {
+    const int e = tid + 256 * i;
+    const int ch = e / (TH * TW / 4), pix = (e - ch * (TH * TW / 4)) * 4;
+    uty[i] = pix / TW;
+    utx[i] = pix - uty[i] * TW;
+    ugo[i] = min(ch, p.Uc - 1) * p.u_cs + uty[i] * p.GW + utx[i];
+    ulo[i] = ch * C::UST + pix;
+  }
+  float4 rv[C::NQV], ru[C::NQU];
+  unsigned okv = 0, oku = 0;
+
+  f32x4 acc[C::MCH / 16][9];
+#pragma unroll
+  for (int s = 0; s < 9; ++s) acc[0][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int tiles = p.tiles_x * p.tiles_y;
+  const long long total = (long long)p.N * tiles;
+  const long long it0 = (long long)chunk * p.items_per_chunk;
+  long long it1 = it0 + p.items_per_chunk;
+  if (it1 > total) it1 = total;
+  const int vb0 = min(nbase, p.Vc - 1);
+
+  // issue: raw loads from clamped (always valid) addresses + validity bits; commit: activation, masks, LDS
+  auto issue = [&](long long it) {
+    const int n = (int)(it / tiles);
+    const int t = (int)(it - (long long)n * tiles);
+    const int tile_y = t / p.tiles_x, tile_x = t - tile_y * p.tiles_x;
+    const int gy0 = tile_y * TH, gx0 = tile_x * TW;
+    const float* vn = p.v + (long long)n * p.v_ns + (long long)vb0 * p.v_cs + gy0 * p.Wv + gx0;
+    const float* un = p.u + (long long)n * p.u_ns + gy0 * p.GW + gx0;
+    unsigned bv = 0, bu = 0;
+#pragma unroll
+    for (int i = 0; i < C::NQV; ++i) {
+      const int r = (vmeta[i] >> 20) & 15, q = (vmeta[i] >> 24) & 15;
+      const int iy = gy0 + r - 1, ix = gx0 + 4 * q - 4;
+      const bool ok = iy >= 0 && iy < p.Hv && ix >= 0 && ix < p.Wv;  // W % 4 == 0: a quad is all-in or all-out
+      bv |= (ok ? 1u : 0u) << i;
+      // invalid quads read the (valid) first quad of the tile instead: offset of (r = 1, q = 1) relative to origin
+      const int off = ok ? vgo[i] : (vgo[i] - ((r - 1) * p.Wv + 4 * q - 4));
+      rv[i] = *reinterpret_cast<const float4*>(vn + off);
+    }
+#pragma unroll
+    for (int i = 0; i < C::NQU; ++i) {
+      const bool ok = gy0 + uty[i] < p.GH && gx0 + utx[i] < p.GW;
+      bu |= (ok ? 1u : 0u) << i;
+      const int off = ok ? ugo[i] : (ugo[i] - (uty[i] * p.GW + utx[i]));
+      ru[i] = *reinterpret_cast<const float4*>(un + off);
+    }
+    okv = bv;
+    oku = bu;
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < C::NQU; ++i) {
+      const bool ok = (oku >> i) & 1u;
+      float* d = ul + ulo[i];
+      *reinterpret_cast<float2*>(d) = make_float2(ok ? ru[i].x : 0.f, ok ? ru[i].y : 0.f);
+      *reinterpret_cast<float2*>(d + 2) = make_float2(ok ? ru[i].z : 0.f, ok ? ru[i].w : 0.f);
+    }
+    constexpr int GRP = 5;
+    static_assert(C::NQV % GRP == 0, "quad groups");
+#pragma unroll
+    for (int g = 0; g < C::NQV; g += GRP) {
+      float2 ab[GRP];
+#pragma unroll
+      for (int j = 0; j < GRP; ++j) {
+        const int ch = (tid + 256 * (g + j)) / C::QPC;
+        ab[j] = *reinterpret_cast<const float2*>(abl + 2 * ch);
+      }
+#pragma unroll
+      for (int j = 0; j < GRP; ++j) {
+        const int i = g + j;
+        const bool ok = (okv >> i) & 1u;  // padding quads -> exact zeros
+        const float4 x = rv[i];
+        float* d = vl + (vmeta[i] & 0xFFFFF);
+        *reinterpret_cast<float2*>(d) = make_float2(ok ? fmaxf(fmaf(ab[j].x, x.x, ab[j].y), 0.f) : 0.f,
+                                                    ok ? fmaxf(fmaf(ab[j].x, x.y, ab[j].y), 0.f) : 0.f);
+        *reinterpret_cast<float2*>(d + 2) = make_float2(ok ? fmaxf(fmaf(ab[j].x, x.z, ab[j].y), 0.f) : 0.f,
+                                                        ok ? fmaxf(fmaf(ab[j].x, x.w, ab[j].y), 0.f) : 0.f);
+      }
+    }
+  };
+
+  if (it0 < it1) issue(it0);
+  for (long long it = it0; it < it1; ++it) {
+    __syncthreads();  // every wave is done reading the previous item (first pass: scale/shift table visible)
+    commit();
+    __syncthreads();
+    if (it + 1 < it1) issue(it + 1);
+    {
+      const float* uw = ul + lj * C::UST + lk;
+      const float* vw = vl + (wave * 16 + lj) * C::VST + lk;
+      constexpr int KPR = TW / 4;
+#pragma unroll 1
+      for (int ty = 0; ty < TH; ++ty) {
+        const float* ur = uw + ty * TW;
+        const float* vr = vw + ty * C::PITCH;
+#pragma unroll 2
+        for (int kx = 0; kx < KPR; ++kx) {
+          const int tx0 = kx * 4;
+          const float a = ur[tx0];
+#pragma unroll
+          for (int s = 0; s < 9; ++s) acc[0][s] = mfma16(a, vr[C::slot_off(s) + tx0], acc[0][s]);
+        }
+      }
+    }
+  }
+
+  float* dst = p.partial + (long long)chunk * p.wsize;
+  const int nch = nbase + wave * 16 + lj;
+#pragma unroll
+  for (int s = 0; s < 9; ++s)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int mch = 4 * lk + r;
+      if (mch < p.Uc && nch < p.Vc) dst[(long long)mch * p.m_stride + (long long)nch * p.n_stride + s] = acc[0][s][r];
+    }
+}
+
+template <int TH, int TW>
+static int wlaunch_q(const WgradParams& p, hipStream_t stream) {
+  using C = WgqCfg<TH, TW>;
+  static bool attr_done = false;
+  auto kern = wgrad_dense_q_k<TH, TW>;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              C::LDS_BYTES);
+    (void)hipGetLastError();
+    attr_done = true;
+    if (getenv("RLN_DEBUG_OCC")) {
+      int nb = -1;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 256, C::LDS_BYTES);
+      fprintf(stderr, "[rln] wgrad_dense_q_k<%dx%d> lds %d B -> %d blocks/CU\n", TH, TW, C::LDS_BYTES, nb);
+    }
+  }
+  dim3 grid((unsigned)p.nchunks, 1u, (unsigned)((p.Vc + 63) / 64));
+  hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, stream, p);
+  return (int)hipGetLastError();
+}
+
 template <int KS, int MT, int PRO, bool SHIFT_A, int TH, int TW>
 static int wlaunch_t(const WgradParams& p, hipStream_t stream) {
   using C = WgCfg<KS, MT, PRO, SHIFT_A, TH, TW>;
@@ -1376,9 +1574,15 @@ void wgrad_block_dims(WgradKind kind, int* m_per_block, int* n_per_block) {
 
 int wgrad_launch(WgradKind kind, int tile, const WgradParams& p, hipStream_t stream) {
   switch (kind) {
-    case WG_DENSE3:
+    case WG_DENSE3: {
+      static const bool noq = getenv("RLN_NO_WGQ") != nullptr;
+      const bool al = ((reinterpret_cast<uintptr_t>(p.u) | reinterpret_cast<uintptr_t>(p.v)) & 15) == 0;
+      const bool q = !noq && al && p.Uc <= 16 && (p.GW % 4) == 0 && p.Wv == p.GW && p.Hv == p.GH &&
+                     (p.u_cs % 4) == 0 && (p.v_cs % 4) == 0 && (p.u_ns % 4) == 0 && (p.v_ns % 4) == 0;
+      if (q) return tile == 0 ? wlaunch_q<4, 32>(p, stream) : wlaunch_q<8, 16>(p, stream);
       return tile == 0 ? wlaunch_t<3, 1, PRO_BNRELU, false, 4, 32>(p, stream)
                        : wlaunch_t<3, 1, PRO_BNRELU, false, 8, 16>(p, stream);
+    }
     case WG_RAW3:
       return tile == 0 ? wlaunch_t<3, 1, PRO_RAW, false, 4, 32>(p, stream)
                        : wlaunch_t<3, 1, PRO_RAW, false, 8, 16>(p, stream);
