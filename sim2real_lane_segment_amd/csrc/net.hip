@@ -523,7 +523,8 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
   const size_t hw0 = (size_t)h * w;
   if (with_bwd) {
     bp_max = std::max(bp_max, (size_t)n * ((hw0 + 255) / 256) * c->cfg.n_classes);
-    wp_max = std::max(wp_max, (size_t)n * c->cfg.n_classes * c->feat_C);
+    wp_max = std::max(wp_max, (size_t)std::max<long long>(n, head_backward_rows(n, (int)hw0)) * c->cfg.n_classes *
+                                  c->feat_C);
   }
   float* stat_partial = cv.take<float>(stat_max);
   unsigned char* pool_idx = cv.take<unsigned char>(pool_bytes);
@@ -1320,11 +1321,17 @@ int rln_backward(rln_ctx* c, float loss_scale, int seg_begin, int seg_end, void*
     q.glin = c->glin;
     q.bias_partial = c->bpartial;
     long long rows = 0;
-    ProfScope ps(c, PC_HEAD_BWD, 2.0 * N * q.h.HW * q.h.C * (3.0 * q.h.ncls + 2), 4.0 * N * q.h.HW * 4.0 * q.h.C, s);
-    RLN_TRY(head_backward_data(q, N, &rows, s));
-    RLN_TRY(reduce_rows(c->bpartial, rows, c->cfg.n_classes, c->grads + c->cls.b, s));
-    RLN_TRY(head_backward_weight(q.h, N, c->glin, c->wpartial, s));
-    RLN_TRY(reduce_rows(c->wpartial, N, (long long)c->cfg.n_classes * c->feat_C, c->grads + c->cls.w, s));
+    ProfScope ps(c, PC_HEAD_BWD, 2.0 * N * q.h.HW * q.h.C * (3.0 * q.h.ncls + 2), 4.0 * N * q.h.HW * 2.0 * q.h.C, s);
+    if (q.h.C <= 512) {  // one pass over the feature stack
+      RLN_TRY(head_backward_fused(q, N, c->wpartial, &rows, s));
+      RLN_TRY(reduce_rows(c->bpartial, rows, c->cfg.n_classes, c->grads + c->cls.b, s));
+      RLN_TRY(reduce_rows(c->wpartial, rows, (long long)c->cfg.n_classes * c->feat_C, c->grads + c->cls.w, s));
+    } else {
+      RLN_TRY(head_backward_data(q, N, &rows, s));
+      RLN_TRY(reduce_rows(c->bpartial, rows, c->cfg.n_classes, c->grads + c->cls.b, s));
+      RLN_TRY(head_backward_weight(q.h, N, c->glin, c->wpartial, s));
+      RLN_TRY(reduce_rows(c->wpartial, N, (long long)c->cfg.n_classes * c->feat_C, c->grads + c->cls.w, s));
+    }
   }
   for (int seg = std::max(seg_begin, 1); seg < seg_end; ++seg) {
     for (int k = (int)c->ops.size() - 1; k >= 0; --k)

@@ -97,6 +97,9 @@ struct HeadBwdParams {
 int head_backward_data(const HeadBwdParams& p, int N, long long* bias_rows, hipStream_t s);
 // dW partial [N][ncls*C]
 int head_backward_weight(const HeadParams& h, int N, const float* glin, float* partial, hipStream_t s);
+// one-pass form: feature gradient + partial rows of dW ([rows][ncls*C]) and db ([rows][ncls]); C <= 512
+long long head_backward_rows(int N, int HW);
+int head_backward_fused(const HeadBwdParams& p, int N, float* wpartial, long long* rows, hipStream_t s);
 
 // ---- EncDecNet pieces (models/EncDecNet.py:29-37,68-69,97,100-112) ----------------------------------------
 // a,b from per-channel (sum, sumsq) of the activated conv output (train) or running stats (eval); updates running stats

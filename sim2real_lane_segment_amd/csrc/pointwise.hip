@@ -665,6 +665,184 @@ int head_backward_weight(const HeadParams& p, int N, const float* glin, float* p
   RLN_LAUNCH_CHECK();
 }
 
+// Fused head backward: ONE pass over the feature stack.  A block walks HEAD_TPB tiles of 32 pixels; each tile's
+// C x 32 feature values are staged in LDS while it (1) recomputes the forward head, (2) writes the gradient of the
+// features (x read from LDS, not a second time from HBM) and (3) adds the tile's share of the classifier weight
+// gradient dW[k][c] += sum_px glin[k][px] * x[c][px] into thread-owned registers.  Per block one partial row of
+// dW (ncls*C) and of db (ncls); a row reduction in fixed order follows (bitwise reproducible).
+// Threads: lane & 31 = pixel of the tile, tid >> 5 = one of 8 channel groups (c = g + 8 i).
+constexpr int HEAD_TPX = 32;   // pixels per tile
+constexpr int HEAD_TPB = 10;   // tiles per block
+constexpr int HEAD_XS = 33;    // LDS row stride of the staged tile (odd: conflict-free for both access patterns)
+
+template <int NC>
+__global__ __launch_bounds__(256) void head_bwd_fused_k(const HeadBwdParams q, float* __restrict__ wpartial) {
+  const HeadParams& p = q.h;
+  extern __shared__ __align__(16) float hsm[];
+  float* wt = hsm;                                  // [C][NC]
+  float* bt = wt + (long long)p.C * NC;             // [NC]
+  float* red = bt + NC;                             // [8][1 + NC][32]
+  float* gls = red + 8 * (1 + NC) * HEAD_TPX;       // [NC][32]   glin = gl * inv
+  float* xs = gls + NC * HEAD_TPX;                  // [C][HEAD_XS]
+  load_head_weights<NC>(wt, bt, p);
+  const int tid = threadIdx.x, pl = tid & 31, g = tid >> 5;
+  const int n = blockIdx.y;
+  const float* Sn = p.S + (long long)n * p.ns;
+  float* Gn = q.G + (long long)n * q.g_ns;
+  float wacc[2][NC], bsum[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) wacc[0][k] = wacc[1][k] = bsum[k] = 0.f;
+  const int ntile = (p.HW + HEAD_TPX - 1) / HEAD_TPX;
+  const int t0 = blockIdx.x * HEAD_TPB, t1 = min(ntile, t0 + HEAD_TPB);
+  for (int tile = t0; tile < t1; ++tile) {
+    __syncthreads();  // previous tile fully consumed (first pass: weights visible)
+    const int px = tile * HEAD_TPX + pl;
+    const bool active = px < p.HW;
+    const int pxs = active ? px : p.HW - 1;
+    // ---- (1) stage + partial dot products of this thread's channels ----
+    float ss = 0.f, d[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) d[k] = 0.f;
+#pragma unroll 4
+    for (int c = g; c < p.C; c += 8) {
+      const float x = Sn[(long long)c * p.HW + pxs];
+      xs[c * HEAD_XS + pl] = x;
+      ss = fmaf(x, x, ss);
+#pragma unroll
+      for (int k = 0; k < NC; ++k) d[k] = fmaf(wt[c * NC + k], x, d[k]);
+    }
+    red[(g * (1 + NC)) * HEAD_TPX + pl] = ss;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) red[(g * (1 + NC) + 1 + k) * HEAD_TPX + pl] = d[k];
+    __syncthreads();
+    ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) d[k] = 0.f;
+#pragma unroll
+    for (int gg = 0; gg < 8; ++gg) {  // fixed order: every group computes the identical per-pixel values
+      ss += red[(gg * (1 + NC)) * HEAD_TPX + pl];
+#pragma unroll
+      for (int k = 0; k < NC; ++k) d[k] += red[(gg * (1 + NC) + 1 + k) * HEAD_TPX + pl];
+    }
+    // ---- per-pixel head: forward recompute, d loss / d logits, back through softmax, /T, normalize ----
+    const float nrm = sqrtf(ss);
+    const bool proj = nrm > 1e-12f;
+    const float inv = 1.f / fmaxf(nrm, 1e-12f);
+    float pr[NC], qq[NC], gp[NC], gl[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) pr[k] = (d[k] * inv + bt[k]) / p.T;
+    softmax_nc<NC>(pr, p.ncls);
+#pragma unroll
+    for (int k = 0; k < NC; ++k) qq[k] = pr[k];
+    softmax_nc<NC>(qq, p.ncls);  // cross_entropy applies log_softmax to the probabilities
+    float dot = 0.f;
+    if (q.mode == 0) {
+      const long long lab = q.y[(long long)n * p.HW + pxs];
+      float wy = 0.f;
+      if (lab >= 0 && lab < p.ncls) wy = q.lossres[4 + (int)lab];
+      const float coef = q.loss_scale * wy / q.lossres[1];
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        gp[k] = (k < p.ncls) ? coef * (qq[k] - ((k == (int)lab) ? 1.f : 0.f)) : 0.f;
+        dot = fmaf(pr[k], gp[k], dot);
+      }
+    } else {  // d/dp of lamda * mean(sum_k p*log(p+1e-5))
+      const float coef = q.loss_scale * q.lamda * q.inv_count;
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        gp[k] = (k < p.ncls) ? coef * (logf(pr[k] + 1e-5f) + pr[k] / (pr[k] + 1e-5f)) : 0.f;
+        dot = fmaf(pr[k], gp[k], dot);
+      }
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      gl[k] = (active && k < p.ncls) ? pr[k] * (gp[k] - dot) / p.T : 0.f;
+      t = fmaf(gl[k], d[k], t);
+    }
+    t = proj ? t * inv : 0.f;  // = sum_c gxn[c] * xn[c]
+    if (g == 0) {
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        gls[k * HEAD_TPX + pl] = gl[k] * inv;
+        bsum[k] += gl[k];
+      }
+    }
+    // ---- (2) feature gradient of this thread's channels ----
+#pragma unroll 4
+    for (int c = g; c < p.C; c += 8) {
+      const float x = xs[c * HEAD_XS + pl];
+      float gxn = 0.f;
+#pragma unroll
+      for (int k = 0; k < NC; ++k) gxn = fmaf(wt[c * NC + k], gl[k], gxn);
+      const float gx = q.feat_sign * (gxn - x * inv * t) * inv;
+      if (active) Gn[(long long)c * p.HW + px] = gx / q.invstd[c];
+    }
+    __syncthreads();  // gls visible
+    // ---- (3) classifier weight gradient: thread-owned channels tid and tid + 256 ----
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+      const int c = tid + 256 * sl;
+      if (c < p.C) {
+#pragma unroll 8
+        for (int j = 0; j < HEAD_TPX; ++j) {
+          const float x = xs[c * HEAD_XS + j];
+#pragma unroll
+          for (int k = 0; k < NC; ++k) wacc[sl][k] = fmaf(gls[k * HEAD_TPX + j], x, wacc[sl][k]);
+        }
+      }
+    }
+  }
+  const long long row = (long long)n * gridDim.x + blockIdx.x;
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) {
+    const int c = tid + 256 * sl;
+    if (c < p.C) {
+#pragma unroll
+      for (int k = 0; k < NC; ++k)
+        if (k < p.ncls) wpartial[(row * p.ncls + k) * p.C + c] = wacc[sl][k];
+    }
+  }
+  if (tid < 64) {  // group 0 = lanes 0..31 of wave 0 hold the bias sums; lanes 32..63 (group 1) contribute 0
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      const float v = wave_sum64(g == 0 ? bsum[k] : 0.f);
+      if (tid == 0 && k < p.ncls) q.bias_partial[row * p.ncls + k] = v;
+    }
+  }
+}
+
+long long head_backward_rows(int N, int HW) {
+  const int ntile = (HW + HEAD_TPX - 1) / HEAD_TPX;
+  return (long long)N * ((ntile + HEAD_TPB - 1) / HEAD_TPB);
+}
+
+// feature gradient + partial rows of dW ([rows][ncls*C]) and db ([rows][ncls]); rows = head_backward_rows(N, HW)
+int head_backward_fused(const HeadBwdParams& q, int N, float* wpartial, long long* rows, hipStream_t s) {
+  const HeadParams& p = q.h;
+  if (p.C > 512 || p.ncls > 16 || p.ncls < 1) return -4;
+  const int ntile = (p.HW + HEAD_TPX - 1) / HEAD_TPX;
+  dim3 grid((unsigned)((ntile + HEAD_TPB - 1) / HEAD_TPB), (unsigned)N);
+  if (rows) *rows = (long long)grid.x * N;
+  auto lds = [&](int nc) { return (size_t)(p.C * nc + nc + 8 * (1 + nc) * HEAD_TPX + nc * HEAD_TPX + p.C * HEAD_XS) * 4; };
+#define RLN_HEAD_FUSED(NCV)                                                                                         \
+  {                                                                                                                 \
+    static bool attr = false;                                                                                       \
+    if (!attr) {                                                                                                    \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head_bwd_fused_k<NCV>),                               \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);                            \
+      (void)hipGetLastError();                                                                                      \
+      attr = true;                                                                                                  \
+    }                                                                                                               \
+    hipLaunchKernelGGL(head_bwd_fused_k<NCV>, grid, dim3(256), lds(NCV), s, q, wpartial);                           \
+  }
+  if (p.ncls <= 4) RLN_HEAD_FUSED(4)
+  else if (p.ncls <= 8) RLN_HEAD_FUSED(8)
+  else RLN_HEAD_FUSED(16)
+#undef RLN_HEAD_FUSED
+  RLN_LAUNCH_CHECK();
+}
+
 // =============================================================================================
 // EncDecNet pieces
 // =============================================================================================
