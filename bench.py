@@ -30,6 +30,32 @@ PEAK_HBM_GBS = 8000.0
 TRAIN_FLOPS_PER_IMAGE = 47_718_689_280  # 3 x 15,906,229,760
 
 
+# kernel-name prefixes of each profiled class in the rocprofv3 --pmc summary (profiles/r01_pmc_traffic.json)
+CLASS_KERNELS = {
+    "dense_conv3x3_fwd": ("void rln::igemm_k<3, 1, 1, 0,",),
+    "dense_conv3x3_dgrad": ("void rln::dgrad_loop_k<",),
+    "dense_conv3x3_wgrad": ("void rln::wgrad_dense_q_k<", "void rln::wgrad_k<3, 1, 1,"),
+}
+
+
+def pmc_traffic(class_name):
+    """HBM bytes per launch of a kernel class from the committed PMC pass (FETCH_SIZE/WRITE_SIZE collected in their
+    own rocprofv3 --pmc runs of this same command and corrected as tools/pmc_traffic.py documents); None if the
+    summary or the class mapping is absent.  Not collected live: counters need the profiler around the process."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    pref = CLASS_KERNELS.get(class_name)
+    if pref is None or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        d = json.load(f)
+    tot, n = 0.0, 0
+    for k, v in d.items():
+        if k.startswith(pref):
+            tot += (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"]
+            n += v["launches"]
+    return round(tot / n) if n else None
+
+
 def read_profile(eng):
     from sim2real_lane_segment_amd import _lib
     L = _lib.lib()
@@ -225,7 +251,9 @@ def main():
                 roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": round(gbs / PEAK_HBM_GBS, 4)}
             roof.update({
-                "kernel": dom["name"], "traffic": None, "launches": dom["launches"],
+                "kernel": dom["name"], "traffic": pmc_traffic(dom["name"]),
+                "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc pass, profiles/r01_pmc_traffic.json)",
+                "alg_bytes_per_launch": round(dom["bytes"] / dom["launches"]), "launches": dom["launches"],
                 "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
                 "share_of_kernel_time": round(dom["ms"] / total_ms, 4),
                 "instrumented_ms_per_step": round(instrumented_ms, 3),

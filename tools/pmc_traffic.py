@@ -15,8 +15,8 @@ import glob
 import json
 import sys
 
-WIDE_READ_KERNELS = ("dgrad_loop_k", "igemm_k<3, 1, 1, 0, 4, 160", "igemm_k<3, 1, 1, 0, 8, 80", "grad_finalize_k",
-                     "head_", "adamw_k", "reduce_rows")
+WIDE_READ_KERNELS = ("dgrad_loop_k", "igemm_k<3, 1, 1, 0, 4, 160", "igemm_k<3, 1, 1, 0, 8, 80",
+                     "igemm_k<3, 1, 1, 0, 4, 80", "wgrad_dense_q_k", "grad_finalize_k", "adamw_k", "reduce_rows")
 
 
 def load(d, counter):
