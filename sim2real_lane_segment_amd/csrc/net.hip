@@ -784,7 +784,8 @@ int finalize_grad_range(rln_ctx* c, int level, int ch_off, int C, const float* n
   return 0;
 }
 
-int run_wgrad(rln_ctx* c, WgradKind kind, WgradParams& w, int Mc, int Nc, int64_t grad_off, hipStream_t s) {
+int run_wgrad(rln_ctx* c, WgradKind kind, WgradParams& w, int Mc, int Nc, int64_t grad_off, hipStream_t s,
+              long long* defer_rows = nullptr) {
   const int pcls = kind == WG_DENSE3 ? PC_DENSE_WGRAD : kind == WG_RAW3 ? PC_FIRST_WGRAD
                    : kind == WG_PW1  ? PC_TD_WGRAD : PC_TU_WGRAD;
   const double taps = (kind == WG_PW1) ? 1.0 : 9.0;
@@ -806,6 +807,10 @@ int run_wgrad(rln_ctx* c, WgradKind kind, WgradParams& w, int Mc, int Nc, int64_
   {
     ProfScope ps(c, pcls, wflops, wbytes, s);
     RLN_TRY(wgrad_launch(kind, tile, w, s));
+  }
+  if (defer_rows) {  // the caller reduces the slabs together with the layer's other small reductions
+    *defer_rows = nch;
+    return 0;
   }
   ProfScope ps2(c, PC_REDUCE, 0, 4.0 * (nch + 1) * w.wsize, s);
   RLN_TRY(reduce_rows(c->wpartial, nch, w.wsize, c->grads + grad_off, s));
@@ -856,7 +861,12 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
     const size_t plane = (size_t)lv.H * lv.W;
     const float* nscale = (o.drop_ch >= 0) ? (c->masks + (size_t)N * o.drop_ch) : nullptr;
     RLN_TRY(finalize_grad_range(c, o.dst_level, o.out_off, o.cout, nscale, &rows, s));
-    RLN_TRY(reduce_rows(c->bpartial, rows, o.cout, c->grads + o.conv.b, s));
+    // dense layers on one stream: the three small reductions of the layer run as ONE launch after the weight gradient
+    static const bool no_tail = getenv("RLN_NO_TAIL") != nullptr;
+    const bool fuse_tail = o.type == OP_DENSE && !c->use_side && !no_tail;
+    DenseTail tail;
+    memset(&tail, 0, sizeof(tail));
+    if (!fuse_tail) RLN_TRY(reduce_rows(c->bpartial, rows, o.cout, c->grads + o.conv.b, s));
     if (o.type == OP_DENSE) {
       IgemmParams p;
       memset(&p, 0, sizeof(p));
@@ -906,10 +916,21 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
           RLN_TRY(igemm_launch(IG_DGRAD3, tile, p, N, s));
         }
       }
-      ProfScope psb(c, PC_BN, 0, 0, s);
-      RLN_TRY(bn_bwd_finalize(c->stat_partial, igemm_stat_blocks(p, N), o.cin,
-                              c->params + o.bn.gamma,
-                              c->grads + o.bn.gamma, c->grads + o.bn.beta, c->S1 + so, c->S2 + so, s));
+      if (fuse_tail) {
+        tail.bn_partial = c->stat_partial;
+        tail.bn_rows = igemm_stat_blocks(p, N);
+        tail.J = o.cin;
+        tail.gamma = c->params + o.bn.gamma;
+        tail.dgamma = c->grads + o.bn.gamma;
+        tail.dbeta = c->grads + o.bn.beta;
+        tail.S1 = c->S1 + so;
+        tail.S2 = c->S2 + so;
+      } else {
+        ProfScope psb(c, PC_BN, 0, 0, s);
+        RLN_TRY(bn_bwd_finalize(c->stat_partial, igemm_stat_blocks(p, N), o.cin,
+                                c->params + o.bn.gamma,
+                                c->grads + o.bn.gamma, c->grads + o.bn.beta, c->S1 + so, c->S2 + so, s));
+      }
     }
     WgradParams w;
     memset(&w, 0, sizeof(w));
@@ -932,7 +953,22 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
       w.v_ns = (long long)lv.C * plane;
       w.pa = c->ab + o.bn.ab;
       w.pb = c->ab + c->n_ab + o.bn.ab;
-      RLN_TRY(run_wgrad(c, WG_DENSE3, w, o.cout, o.cin, o.conv.w, ws));
+      if (fuse_tail) {
+        long long wrows = 0;
+        RLN_TRY(run_wgrad(c, WG_DENSE3, w, o.cout, o.cin, o.conv.w, ws, &wrows));
+        tail.w_src = c->wpartial;
+        tail.w_rows = wrows;
+        tail.w_len = w.wsize;
+        tail.w_dst = c->grads + o.conv.w;
+        tail.b_src = c->bpartial;
+        tail.b_rows = rows;
+        tail.b_len = o.cout;
+        tail.b_dst = c->grads + o.conv.b;
+        ProfScope pst(c, PC_REDUCE, 0, 4.0 * (wrows + 1) * w.wsize, s);
+        RLN_TRY(dense_tail(tail, s));
+      } else {
+        RLN_TRY(run_wgrad(c, WG_DENSE3, w, o.cout, o.cin, o.conv.w, ws));
+      }
     } else {
       w.v = c->last_x;
       w.v_ns = (long long)o.cin * plane;

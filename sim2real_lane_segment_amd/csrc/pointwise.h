@@ -48,6 +48,15 @@ int splitk_finish(const float* part, int nsplit, long long split_stride, int N, 
                   hipStream_t s);
 
 // dst[e] = sum_r src[r*len + e]   (fixed order)
+// end of a dense layer's backward: bn_bwd_finalize + reduce_rows(weight slabs) + reduce_rows(bias rows), one launch
+struct DenseTail {
+  const float* bn_partial; long long bn_rows; int J;
+  const float* gamma; float* dgamma; float* dbeta; float* S1; float* S2;
+  const float* w_src; long long w_rows, w_len; float* w_dst;
+  const float* b_src; long long b_rows, b_len; float* b_dst;
+  long long nA, nB; int w_tall, b_tall;  // filled by dense_tail()
+};
+int dense_tail(DenseTail t, hipStream_t s);
 int reduce_rows(const float* src, long long rows, long long len, float* dst, hipStream_t s);
 
 // ---- head ----------------------------------------------------------------------------------

@@ -80,11 +80,11 @@ int bn_prep(int training, int C, const float* gamma, const float* beta, const fl
   RLN_LAUNCH_CHECK();
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_k(const float* __restrict__ partial, long long nblk, int J,
-                                                         const float* __restrict__ gamma, float* dgamma, float* dbeta,
-                                                         float* S1, float* S2) {
+__device__ __forceinline__ void bn_bwd_finalize_body(int vb, const float* __restrict__ partial, long long nblk, int J,
+                                                     const float* __restrict__ gamma, float* dgamma, float* dbeta,
+                                                     float* S1, float* S2) {
   const int lane = threadIdx.x & 63;
-  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int j = vb * 4 + (threadIdx.x >> 6);
   if (j >= J) return;
   double s1 = 0.0, s2 = 0.0;
   for (long long b = lane; b < nblk; b += 64) {
@@ -103,6 +103,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_k(const float* __restrict
     S1[j] += g * (float)s1;
     S2[j] += g * (float)s2;
   }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_k(const float* __restrict__ partial, long long nblk, int J,
+                                                         const float* __restrict__ gamma, float* dgamma, float* dbeta,
+                                                         float* S1, float* S2) {
+  bn_bwd_finalize_body((int)blockIdx.x, partial, nblk, J, gamma, dgamma, dbeta, S1, S2);
 }
 
 int bn_bwd_finalize(const float* partial, long long nblk, int J, const float* gamma, float* dgamma, float* dbeta,
@@ -227,9 +233,9 @@ int splitk_finish(const float* part, int nsplit, long long split_stride, int N, 
   RLN_LAUNCH_CHECK();
 }
 
-__global__ __launch_bounds__(256) void reduce_rows_k(const float* __restrict__ src, long long rows, long long len,
-                                                     float* dst) {
-  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void reduce_rows_body(long long vb, const float* __restrict__ src, long long rows,
+                                                 long long len, float* dst) {
+  const long long e = vb * 256 + threadIdx.x;
   if (e >= len) return;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   long long r = 0;
@@ -243,11 +249,16 @@ __global__ __launch_bounds__(256) void reduce_rows_k(const float* __restrict__ s
   dst[e] = (a0 + a1) + (a2 + a3);
 }
 
+__global__ __launch_bounds__(256) void reduce_rows_k(const float* __restrict__ src, long long rows, long long len,
+                                                     float* dst) {
+  reduce_rows_body((long long)blockIdx.x, src, rows, len, dst);
+}
+
 // few long columns (bias gradients): one wave per column, double accumulation
-__global__ __launch_bounds__(256) void reduce_rows_tall_k(const float* __restrict__ src, long long rows, long long len,
-                                                          float* dst) {
+__device__ __forceinline__ void reduce_rows_tall_body(long long vb, const float* __restrict__ src, long long rows,
+                                                      long long len, float* dst) {
   const int lane = threadIdx.x & 63;
-  const long long e = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long e = vb * 4 + (threadIdx.x >> 6);
   if (e >= len) return;
   double a = 0.0;
   for (long long r = lane; r < rows; r += 64) a += (double)src[r * len + e];
@@ -256,8 +267,46 @@ __global__ __launch_bounds__(256) void reduce_rows_tall_k(const float* __restric
   if (lane == 0) dst[e] = (float)a;
 }
 
+__global__ __launch_bounds__(256) void reduce_rows_tall_k(const float* __restrict__ src, long long rows, long long len,
+                                                          float* dst) {
+  reduce_rows_tall_body((long long)blockIdx.x, src, rows, len, dst);
+}
+
+// The three small reductions that end a dense layer's backward (BatchNorm-backward sums of the data gradient, the
+// weight-gradient slabs, the bias-gradient rows) in ONE launch: they are independent, and as separate launches
+// each costs a ~5 us dependent-dispatch gap on top of its few microseconds of work.  Same arithmetic and
+// summation order as the stand-alone kernels.
+__global__ __launch_bounds__(256) void dense_tail_k(const DenseTail t) {
+  long long b = blockIdx.x;
+  if (b < t.nA) {
+    bn_bwd_finalize_body((int)b, t.bn_partial, t.bn_rows, t.J, t.gamma, t.dgamma, t.dbeta, t.S1, t.S2);
+    return;
+  }
+  b -= t.nA;
+  if (b < t.nB) {
+    if (t.w_tall) reduce_rows_tall_body(b, t.w_src, t.w_rows, t.w_len, t.w_dst);
+    else reduce_rows_body(b, t.w_src, t.w_rows, t.w_len, t.w_dst);
+    return;
+  }
+  b -= t.nB;
+  if (t.b_tall) reduce_rows_tall_body(b, t.b_src, t.b_rows, t.b_len, t.b_dst);
+  else reduce_rows_body(b, t.b_src, t.b_rows, t.b_len, t.b_dst);
+}
+
+static inline bool rows_tall(long long rows, long long len) { return len <= 4096 && rows >= 64; }
+
+int dense_tail(DenseTail t, hipStream_t s) {
+  t.nA = (t.J + 3) / 4;
+  t.w_tall = rows_tall(t.w_rows, t.w_len) ? 1 : 0;
+  t.b_tall = rows_tall(t.b_rows, t.b_len) ? 1 : 0;
+  t.nB = t.w_tall ? (t.w_len + 3) / 4 : (t.w_len + 255) / 256;
+  const long long nC = t.b_tall ? (t.b_len + 3) / 4 : (t.b_len + 255) / 256;
+  hipLaunchKernelGGL(dense_tail_k, dim3((unsigned)(t.nA + t.nB + nC)), dim3(256), 0, s, t);
+  RLN_LAUNCH_CHECK();
+}
+
 int reduce_rows(const float* src, long long rows, long long len, float* dst, hipStream_t s) {
-  if (len <= 4096 && rows >= 64) {
+  if (rows_tall(rows, len)) {
     hipLaunchKernelGGL(reduce_rows_tall_k, dim3((unsigned)((len + 3) / 4)), dim3(256), 0, s, src, rows, len, dst);
   } else {
     hipLaunchKernelGGL(reduce_rows_k, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s, src, rows, len, dst);
