@@ -67,6 +67,7 @@ enum IgemmKind {
   IG_CONV1_BN = 6,   // KS1 NT4 PRO_BNRELU EPI_STORE   1x1 conv without pool (generic / tests)
   IG_CONV7_RAW = 7,  // KS7 NT1 PRO_RAW    EPI_STORE   EncDecNet 7x7 convolutions
   IG_CONV1_RAW = 8,  // KS1 NT1 PRO_RAW    EPI_STORE   EncDecNet 1x1 classifier
+  IG_CONVT4 = 9,     // KS3 NT1 PRO_RAW    EPI_STORE   convT forward, all four output-parity classes per block (ncls = 1, TM_ID)
 };
 
 // tile: 0 -> 8x32, 1 -> 16x16

@@ -79,8 +79,42 @@ __device__ __forceinline__ void igemm_compute(const float* __restrict__ zbase, c
   }
 }
 
-template <int KS, int NT, int PRO, int EPI, int TH, int TW, bool CLS, bool V4>
-__global__ __launch_bounds__(256, ((NT == 1 && TH * TW <= 256) ? 4 : ((NT == 1 && TH * TW <= 320) ? 3 : 2)))
+// ConvTranspose2d(k3, s2) forward, all four output-parity classes from ONE staged input tile: out[2y+py][2x+px]
+// takes the taps (ky, kx) of matching parity, ky = py + 2*(1 - sy) for the input rows y - 1 + sy, sy in {0, 1}
+// (sy = 0 only when py = 0); likewise in x.  Nine MFMAs per (pixel tile, 4-channel group), four shifted reads.
+// The per-class accumulation order equals the one-class-per-block form (slots ascending), so results are
+// bit-identical to it.  Weight slab slot = kernel tap (TM_ID staging).
+template <typename C, int TW>
+__device__ __forceinline__ void igemm_compute_convt4(const float* __restrict__ zbase, const float* __restrict__ wlane,
+                                                     f32x4 (&acc)[4][C::MPW][1]) {
+#pragma unroll 1
+  for (int kg = 0; kg < 4; ++kg) {
+    const float* zk = zbase + kg * 4 * C::CHS;
+    const float* wk = wlane + kg * C::NS * 64;
+    float bw[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) bw[t] = wk[t * 64];
+#pragma unroll
+    for (int m = 0; m < C::MPW; ++m) {
+      const float* zm = zk + ((m * 16) / TW) * C::PITCH + (m * 16) % TW;
+      const float a00 = zm[C::slot_off(0)], a01 = zm[C::slot_off(1)], a10 = zm[C::slot_off(3)], a11 = zm[C::slot_off(4)];
+      acc[0][m][0] = mfma16(a00, bw[8], acc[0][m][0]);
+      acc[0][m][0] = mfma16(a01, bw[6], acc[0][m][0]);
+      acc[0][m][0] = mfma16(a10, bw[2], acc[0][m][0]);
+      acc[0][m][0] = mfma16(a11, bw[0], acc[0][m][0]);
+      acc[1][m][0] = mfma16(a01, bw[7], acc[1][m][0]);
+      acc[1][m][0] = mfma16(a11, bw[1], acc[1][m][0]);
+      acc[2][m][0] = mfma16(a10, bw[5], acc[2][m][0]);
+      acc[2][m][0] = mfma16(a11, bw[3], acc[2][m][0]);
+      acc[3][m][0] = mfma16(a11, bw[4], acc[3][m][0]);
+    }
+  }
+}
+
+// CLS: 0 plain convolution; 1 ConvTranspose2d forward, one output-parity class per block (grid.x = 4 * tiles);
+//      2 ConvTranspose2d forward, all four classes per block (NT = 1)
+template <int KS, int NT, int PRO, int EPI, int TH, int TW, int CLS, bool V4>
+__global__ __launch_bounds__(256, ((NT == 1 && TH * TW <= 256 && CLS != 2) ? 4 : ((NT == 1 && TH * TW <= 320) ? 3 : 2)))
     void igemm_k(const IgemmParams p) {
   using C = IgCfg<KS, NT, PRO, EPI, TH, TW, V4>;
   static_assert(!V4 || (PRO != PRO_S2D && C::CHS % 4 == 0 && C::PITCH % 4 == 0), "V4 needs 16-byte aligned LDS rows");
@@ -114,7 +148,7 @@ __global__ __launch_bounds__(256, ((NT == 1 && TH * TW <= 256) ? 4 : ((NT == 1 &
   int bx = bx0;
   const int tiles = p.tiles_x * p.tiles_y;
   int cls = 0;
-  if constexpr (CLS) {
+  if constexpr (CLS == 1) {
     cls = bx / tiles;
     bx -= cls * tiles;
   }
@@ -158,11 +192,16 @@ __global__ __launch_bounds__(256, ((NT == 1 && TH * TW <= 256) ? 4 : ((NT == 1 &
   const float* zbase = zl + lk * C::CHS + ((wave * MPW * 16) / TW) * C::PITCH + lj;
   const float* wlane = wl + lane;
 
-  f32x4 acc[MPW][NT];
+  constexpr int NCL = (CLS == 2) ? 4 : 1;  // accumulator sets (output-parity classes computed by this block)
+  static_assert(CLS != 2 || (NT == 1 && KS == 3 && EPI == EPI_STORE && PRO == PRO_RAW), "fused classes: convT forward");
+  f32x4 accs[NCL][MPW][NT];
+  f32x4(&acc)[MPW][NT] = accs[0];
 #pragma unroll
-  for (int m = 0; m < MPW; ++m)
+  for (int cl = 0; cl < NCL; ++cl)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < MPW; ++m)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) accs[cl][m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const float* in_n = p.in + (long long)n * p.in_ns;
   const int nchunk = (p.K + 15) >> 4;
@@ -384,7 +423,9 @@ __global__ __launch_bounds__(256, ((NT == 1 && TH * TW <= 256) ? 4 : ((NT == 1 &
     stamp(t_issue);
     if (dbg & 4) continue;
     // ---- MFMA (channels past K are zero-filled in LDS, so all four 4-channel groups always run) ----
-    if constexpr (CLS) {  // ConvTranspose2d output parity class: only the taps with matching parity exist
+    if constexpr (CLS == 2) {
+      igemm_compute_convt4<C, TW>(zbase, wlane, accs);
+    } else if constexpr (CLS == 1) {  // ConvTranspose2d output parity class: only the taps with matching parity exist
       switch (cls) {
         case 0: igemm_compute<C, NT, TW, 0x1Bull>(zbase, wlane, acc); break;
         case 1: igemm_compute<C, NT, TW, 0x12ull>(zbase, wlane, acc); break;
@@ -411,7 +452,7 @@ __global__ __launch_bounds__(256, ((NT == 1 && TH * TW <= 256) ? 4 : ((NT == 1 &
   const long long blk_lin = (long long)n * gridDim.x + bx0;
 
   if constexpr (EPI == EPI_STORE || EPI == EPI_DGRAD) {
-    constexpr int S_ = CLS ? 2 : 1;
+    constexpr int S_ = (CLS != 0) ? 2 : 1;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int j = jbase + nt * 16 + lj;
@@ -437,87 +478,92 @@ __global__ __launch_bounds__(256, ((NT == 1 && TH * TW <= 256) ? 4 : ((NT == 1 &
         accum = (j >= p.acc_lo) && (j < p.acc_hi);
       }
 #pragma unroll
-      for (int m = 0; m < MPW; ++m) {
-        const int q = (wave * MPW + m) * 16 + lk * 4;
-        const int ty = q / TW, tx = q - ty * TW;
-        const int gy = gy0 + ty, gx = gx0 + tx;
-        if (!jv || gy >= p.GH) continue;
-        if constexpr (EPI == EPI_STORE) {
-          const int oy = gy * S_ + py;
-          if (oy >= p.Hout) continue;
-          float* dst = p.out + (long long)ky * p.split_stride + (long long)n * p.out_ns + (long long)j * p.out_cs +
-                       (long long)oy * p.Wout;
-          const int ox0 = gx * S_ + px;
-          float v[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float t = acc[m][nt][r] + bias_j;
-            if (p.act != 0) {  // uniform; EncDecNet's Conv = conv -> activation (models/EncDecNet.py:29-33)
-              if (p.act == 1) t = fmaxf(t, 0.f);
-              else if (p.act == 2) t = t > 0.f ? t : p.act_param * t;
-              else if (p.act == 3) t = 1.f / (1.f + expf(-t));
-              else t = tanhf(t);
-            }
-            v[r] = t * sc;
-          }
-          if (S_ == 1 && p.out_vec && ox0 + 3 < p.Wout) {
-            *reinterpret_cast<float4*>(dst + ox0) = make_float4(v[0], v[1], v[2], v[3]);
-#pragma unroll
+      for (int cl = 0; cl < NCL; ++cl) {  // output-parity classes held by this block (1 unless CLS == 2)
+        const int pyc = (CLS == 2) ? (cl >> 1) : py, pxc = (CLS == 2) ? (cl & 1) : px;
+        f32x4(&accc)[MPW][NT] = accs[cl];
+  #pragma unroll
+        for (int m = 0; m < MPW; ++m) {
+          const int q = (wave * MPW + m) * 16 + lk * 4;
+          const int ty = q / TW, tx = q - ty * TW;
+          const int gy = gy0 + ty, gx = gx0 + tx;
+          if (!jv || gy >= p.GH) continue;
+          if constexpr (EPI == EPI_STORE) {
+            const int oy = gy * S_ + pyc;
+            if (oy >= p.Hout) continue;
+            float* dst = p.out + (long long)ky * p.split_stride + (long long)n * p.out_ns + (long long)j * p.out_cs +
+                         (long long)oy * p.Wout;
+            const int ox0 = gx * S_ + pxc;
+            float v[4];
+  #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              s1 += v[r];
-              s2 += v[r] * v[r];
+              float t = accc[m][nt][r] + bias_j;
+              if (p.act != 0) {  // uniform; EncDecNet's Conv = conv -> activation (models/EncDecNet.py:29-33)
+                if (p.act == 1) t = fmaxf(t, 0.f);
+                else if (p.act == 2) t = t > 0.f ? t : p.act_param * t;
+                else if (p.act == 3) t = 1.f / (1.f + expf(-t));
+                else t = tanhf(t);
+              }
+              v[r] = t * sc;
             }
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int ox = ox0 + r * S_;
-              if (gx + r < p.GW && ox < p.Wout) {
-                dst[ox] = v[r];
+            if (S_ == 1 && p.out_vec && ox0 + 3 < p.Wout) {
+              *reinterpret_cast<float4*>(dst + ox0) = make_float4(v[0], v[1], v[2], v[3]);
+  #pragma unroll
+              for (int r = 0; r < 4; ++r) {
                 s1 += v[r];
                 s2 += v[r] * v[r];
               }
-            }
-          }
-        } else {
-          const long long rowoff = (long long)j * p.out_cs + (long long)gy * p.GW + gx;
-          const float* sp = p.S + (long long)n * p.s_ns + rowoff;
-          float* gp = p.out + (long long)n * p.out_ns + rowoff;
-          float sv[4], gv[4];
-          const bool vec = p.out_vec && (gx + 3 < p.GW);
-          if (vec) {
-            const float4 t4 = *reinterpret_cast<const float4*>(sp);
-            sv[0] = t4.x; sv[1] = t4.y; sv[2] = t4.z; sv[3] = t4.w;
-            if (accum) {
-              const float4 g4 = *reinterpret_cast<const float4*>(gp);
-              gv[0] = g4.x; gv[1] = g4.y; gv[2] = g4.z; gv[3] = g4.w;
             } else {
-              gv[0] = gv[1] = gv[2] = gv[3] = 0.f;
+  #pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int ox = ox0 + r * S_;
+                if (gx + r < p.GW && ox < p.Wout) {
+                  dst[ox] = v[r];
+                  s1 += v[r];
+                  s2 += v[r] * v[r];
+                }
+              }
             }
           } else {
-#pragma unroll
+            const long long rowoff = (long long)j * p.out_cs + (long long)gy * p.GW + gx;
+            const float* sp = p.S + (long long)n * p.s_ns + rowoff;
+            float* gp = p.out + (long long)n * p.out_ns + rowoff;
+            float sv[4], gv[4];
+            const bool vec = p.out_vec && (gx + 3 < p.GW);
+            if (vec) {
+              const float4 t4 = *reinterpret_cast<const float4*>(sp);
+              sv[0] = t4.x; sv[1] = t4.y; sv[2] = t4.z; sv[3] = t4.w;
+              if (accum) {
+                const float4 g4 = *reinterpret_cast<const float4*>(gp);
+                gv[0] = g4.x; gv[1] = g4.y; gv[2] = g4.z; gv[3] = g4.w;
+              } else {
+                gv[0] = gv[1] = gv[2] = gv[3] = 0.f;
+              }
+            } else {
+  #pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const bool ok = gx + r < p.GW;
+                sv[r] = ok ? sp[r] : 0.f;
+                gv[r] = (ok && accum) ? gp[r] : 0.f;
+              }
+            }
+            float ov[4];
+  #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const bool ok = gx + r < p.GW;
-              sv[r] = ok ? sp[r] : 0.f;
-              gv[r] = (ok && accum) ? gp[r] : 0.f;
+              const float yv = fmaf(ea, sv[r], eb);
+              const float gyv = (ok && yv > 0.f) ? accc[m][nt][r] : 0.f;
+              const float xh = (sv[r] - emean) * einv;
+              s1 += gyv;
+              s2 += gyv * xh;
+              ov[r] = fmaf(egam, gyv, gv[r]);
             }
-          }
-          float ov[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const bool ok = gx + r < p.GW;
-            const float yv = fmaf(ea, sv[r], eb);
-            const float gyv = (ok && yv > 0.f) ? acc[m][nt][r] : 0.f;
-            const float xh = (sv[r] - emean) * einv;
-            s1 += gyv;
-            s2 += gyv * xh;
-            ov[r] = fmaf(egam, gyv, gv[r]);
-          }
-          if (vec) {
-            *reinterpret_cast<float4*>(gp) = make_float4(ov[0], ov[1], ov[2], ov[3]);
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (gx + r < p.GW) gp[r] = ov[r];
+            if (vec) {
+              *reinterpret_cast<float4*>(gp) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+            } else {
+  #pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (gx + r < p.GW) gp[r] = ov[r];
+            }
           }
         }
       }
@@ -598,13 +644,13 @@ __global__ __launch_bounds__(256, ((NT == 1 && TH * TW <= 256) ? 4 : ((NT == 1 &
   }
 }
 
-template <int KS, int NT, int PRO, int EPI, int TH, int TW, bool CLS, bool V4>
+template <int KS, int NT, int PRO, int EPI, int TH, int TW, int CLS, bool V4>
 static int launch_v(const IgemmParams& p, int N, hipStream_t stream) {
   using C = IgCfg<KS, NT, PRO, EPI, TH, TW, V4>;
   if (C::AB_FLOATS > 0 && p.K > C::AB_MAX) return -4;
   static bool attr_done = false;
   auto kern = igemm_k<KS, NT, PRO, EPI, TH, TW, CLS, V4>;
-  if ((p.ncls > 1) != CLS) return -1;
+  if ((p.ncls > 1) != (CLS == 1)) return -1;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               C::LDS_BYTES);
@@ -634,7 +680,7 @@ static int launch_v(const IgemmParams& p, int N, hipStream_t stream) {
 }
 
 // picks the 16-byte staging variant when the K-side operand allows it
-template <int KS, int NT, int PRO, int EPI, int TH, int TW, bool CLS = false>
+template <int KS, int NT, int PRO, int EPI, int TH, int TW, int CLS = 0>
 static int launch_t(const IgemmParams& p, int N, hipStream_t stream) {
   if constexpr (PRO != PRO_S2D) {
     // measured: on the small tiles the 16-byte staging path is not faster than the scalar one (the tile-with-halo
@@ -698,15 +744,18 @@ int igemm_pick_tile(int gh, int gw) {
 int igemm_launch(IgemmKind kind, int tile, const IgemmParams& p, int N, hipStream_t stream) {
   switch (kind) {
     case IG_CONV3_BN:
-      if (tile == 2) return launch_v<3, 1, PRO_BNRELU, EPI_STORE, 4, 160, false, true>(p, N, stream);
-      if (tile == 3) return launch_v<3, 1, PRO_BNRELU, EPI_STORE, 8, 80, false, true>(p, N, stream);
-      if (tile == 4) return launch_v<3, 1, PRO_BNRELU, EPI_STORE, 4, 80, false, true>(p, N, stream);
+      if (tile == 2) return launch_v<3, 1, PRO_BNRELU, EPI_STORE, 4, 160, 0, true>(p, N, stream);
+      if (tile == 3) return launch_v<3, 1, PRO_BNRELU, EPI_STORE, 8, 80, 0, true>(p, N, stream);
+      if (tile == 4) return launch_v<3, 1, PRO_BNRELU, EPI_STORE, 4, 80, 0, true>(p, N, stream);
       return tile == 0 ? launch_t<3, 1, PRO_BNRELU, EPI_STORE, 8, 32>(p, N, stream)
                        : launch_t<3, 1, PRO_BNRELU, EPI_STORE, 16, 16>(p, N, stream);
+    case IG_CONVT4:
+      return tile == 0 ? launch_t<3, 1, PRO_RAW, EPI_STORE, 8, 32, 2>(p, N, stream)
+                       : launch_t<3, 1, PRO_RAW, EPI_STORE, 16, 16, 2>(p, N, stream);
     case IG_CONV3_RAW:
       if (p.ncls > 1)
-        return tile == 0 ? launch_t<3, 1, PRO_RAW, EPI_STORE, 8, 32, true>(p, N, stream)
-                         : launch_t<3, 1, PRO_RAW, EPI_STORE, 16, 16, true>(p, N, stream);
+        return tile == 0 ? launch_t<3, 1, PRO_RAW, EPI_STORE, 8, 32, 1>(p, N, stream)
+                         : launch_t<3, 1, PRO_RAW, EPI_STORE, 16, 16, 1>(p, N, stream);
       return tile == 0 ? launch_t<3, 1, PRO_RAW, EPI_STORE, 8, 32>(p, N, stream)
                        : launch_t<3, 1, PRO_RAW, EPI_STORE, 16, 16>(p, N, stream);
     case IG_CONV1_POOL:

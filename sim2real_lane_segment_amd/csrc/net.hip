@@ -619,6 +619,11 @@ int prep_bn(rln_ctx* c, const Op& o, int training, hipStream_t s) {
   return 0;
 }
 
+static bool convt_fused() {
+  static const bool off = getenv("RLN_NO_CONVT4") != nullptr;
+  return !off;
+}
+
 int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
   const Op& o = c->ops[k];
   const int N = c->N;
@@ -693,6 +698,11 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
     p.w_js = 9;
     p.tapmode = TM_CONVT;
     p.ncls = 4;
+    if (convt_fused()) {  // all four output-parity classes from one staged input tile
+      kind = IG_CONVT4;
+      p.tapmode = TM_ID;
+      p.ncls = 1;
+    }
     p.GH = (dl.H + 1) / 2;
     p.GW = (dl.W + 1) / 2;
   }
@@ -1454,6 +1464,10 @@ int rln_op_convt(const float* x, int n, int cin, int h, int w, const float* weig
   p.w_js = 9;
   p.tapmode = TM_CONVT;
   p.ncls = 4;
+  if (convt_fused()) {
+    p.tapmode = TM_ID;
+    p.ncls = 1;
+  }
   p.J = cout;
   p.GH = (hout + 1) / 2;
   p.GW = (wout + 1) / 2;
@@ -1468,7 +1482,7 @@ int rln_op_convt(const float* x, int n, int cin, int h, int w, const float* weig
   igemm_tile_dims(IG_CONV3_RAW, tile, &th, &tw);
   p.tiles_y = (p.GH + th - 1) / th;
   p.tiles_x = (p.GW + tw - 1) / tw;
-  RLN_TRY(igemm_launch(IG_CONV3_RAW, tile, p, n, (hipStream_t)stream));
+  RLN_TRY(igemm_launch(p.ncls == 1 ? IG_CONVT4 : IG_CONV3_RAW, tile, p, n, (hipStream_t)stream));
   return 0;
 }
 
