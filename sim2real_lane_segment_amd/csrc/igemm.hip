@@ -770,8 +770,16 @@ int igemm_launch(IgemmKind kind, int tile, const IgemmParams& p, int N, hipStrea
     case IG_DGRAD1:
       return tile == 0 ? launch_t<1, 4, PRO_RAW, EPI_DGRAD, 8, 32>(p, N, stream)
                        : launch_t<1, 4, PRO_RAW, EPI_DGRAD, 16, 16>(p, N, stream);
-    case IG_S2D3:
+    case IG_S2D3: {
+      // output-channel tiles per block.  80 channels: 2 x 48 wastes 17 % of the MFMA columns (2 x 64: 38 %) and keeps
+      // two blocks per CU; 1 x 80 fits only one block per CU and measured slower (1.72 vs 1.40 ms/step).
+      static const int force = getenv("RLN_S2D_NT") ? atoi(getenv("RLN_S2D_NT")) : 0;
+      const int waste4 = (p.J + 63) / 64 * 64 - p.J, waste3 = (p.J + 47) / 48 * 48 - p.J;
+      const int nt = force ? force : (waste3 < waste4 ? 3 : 4);
+      if (nt == 5) return launch_t<3, 5, PRO_S2D, EPI_STORE, 8, 16>(p, N, stream);
+      if (nt == 3) return launch_t<3, 3, PRO_S2D, EPI_STORE, 8, 16>(p, N, stream);
       return launch_t<3, 4, PRO_S2D, EPI_STORE, 8, 16>(p, N, stream);
+    }
     case IG_CONV7_RAW:
       return tile == 0 ? launch_v<7, 1, PRO_RAW, EPI_STORE, 8, 32, false, false>(p, N, stream)
                        : launch_v<7, 1, PRO_RAW, EPI_STORE, 16, 16, false, false>(p, N, stream);
