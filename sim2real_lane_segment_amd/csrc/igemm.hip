@@ -1445,6 +1445,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_dense_q_k(const WgradParams p) {
   }
   float4 rv[C::NQV], ru[C::NQU];
   unsigned okv = 0, oku = 0;
+  // Partial last channel group (Vc % 64 != 0): staging passes that hold only channels >= Vc are skipped, and so is
+  // the MFMA phase of waves whose 16 channels are all >= Vc (their LDS rows are then never read).  Over the
+  // layers of FCDenseNet67 14 % of the 64-channel slots are such padding.
+  const int nvalid = min(C::NCH, p.Vc - nbase);                       // >= 1
+  const int nqv = min(C::NQV, (nvalid * C::QPC + 255) / 256);         // passes that touch a valid channel
+  const bool wave_live = wave * 16 < nvalid;
 
   f32x4 acc[C::MCH / 16][9];
 #pragma unroll
@@ -1468,6 +1474,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dense_q_k(const WgradParams p) {
     unsigned bv = 0, bu = 0;
 #pragma unroll
     for (int i = 0; i < C::NQV; ++i) {
+      if (i >= nqv) break;  // uniform
       const int r = (vmeta[i] >> 20) & 15, q = (vmeta[i] >> 24) & 15;
       const int iy = gy0 + r - 1, ix = gx0 + 4 * q - 4;
       const bool ok = iy >= 0 && iy < p.Hv && ix >= 0 && ix < p.Wv;  // W % 4 == 0: a quad is all-in or all-out
@@ -1507,6 +1514,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dense_q_k(const WgradParams p) {
 #pragma unroll
       for (int j = 0; j < GRP; ++j) {
         const int i = g + j;
+        if (i >= nqv) break;  // uniform
         const bool ok = (okv >> i) & 1u;  // padding quads -> exact zeros
         const float4 x = rv[i];
         float* d = vl + (vmeta[i] & 0xFFFFF);
@@ -1524,7 +1532,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dense_q_k(const WgradParams p) {
     commit();
     __syncthreads();
     if (it + 1 < it1) issue(it + 1);
-    {
+    if (wave_live) {
       const float* uw = ul + lj * C::UST + lk;
       const float* vw = vl + (wave * 16 + lj) * C::VST + lk;
       constexpr int KPR = TW / 4;
