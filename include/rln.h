@@ -188,6 +188,15 @@ int rln_op_bn_drop_upsample2(const float* x, int n, int c, int h, int w, const f
 int rln_op_softmax_channels(const float* x, int n, int c, int hw, float* out, void* stream);
 int rln_op_dropout_mask(float* dst, int64_t count, float keep, uint64_t seed, void* stream);
 
+/* rln_preprocess_u8: the non-augmenting input transform of dataManagement/myTransforms.py:15-19 on device:
+ * Resize(h, w) [bilinear, cv2 INTER_LINEAR fixed point for 8-bit] -> optional ToGray -> Normalize(mean, std, 255) ->
+ * CHW float32; labels (may be null together with y) are resized with nearest neighbour (cv2 INTER_NEAREST) to int64.
+ * frames: [n][hs][ws][3] uint8 in the stored channel order (the reference normalises BGR frames with the RGB
+ * constants, myDatasets.py:51); mean3/std3: HOST pointers to 3 floats; x: [n][3][h][w]; y: [n][h][w].
+ * Parity of this row is unpinned (cv2/albumentations are not available to the reference here). */
+int rln_preprocess_u8(const uint8_t* frames, int n, int hs, int ws, const uint8_t* labels, int h, int w, int gray,
+                      const float* mean3, const float* std3, float* x, int64_t* y, void* stream);
+
 /* rln_op_classifier: FCDenseNetClassifier.forward on caller-provided weights (tiramisu.py:120-125):
  * out[n,k,p] = softmax_k((sum_c w[k,c]*feat[n,c,p] + b[k]) / T). */
 int rln_op_classifier(const float* feat, int n, int c, int hw, const float* w, const float* b, int ncls, float T,

@@ -24,3 +24,7 @@ def install_aliases():
     sys.modules.setdefault("trainingModules.TrainingBase", TrainingBase)
     sys.modules.setdefault("trainingModules.SimpleTrain", SimpleTrain)
     sys.modules.setdefault("trainingModules.MMETrainingModule", MMETrainingModule)
+    from . import dataManagement
+    from .dataManagement import myTransforms
+    sys.modules.setdefault("dataManagement", dataManagement)
+    sys.modules.setdefault("dataManagement.myTransforms", myTransforms)

@@ -893,6 +893,80 @@ int head_backward_fused(const HeadBwdParams& q, int N, float* wpartial, long lon
 }
 
 // =============================================================================================
+// Input transform on device (dataManagement/myTransforms.py:15-19, non-augmenting branch):
+// Resize(height, width) -> [ToGray] -> Normalize() -> ToTensorV2, for uint8 HWC frames resident in HBM; the label
+// mask is resized with nearest neighbour.  Resize follows the published fixed-point algorithm of cv2.resize
+// INTER_LINEAR for 8-bit images (the library albumentations 0.5.2 calls; neither ships with the reference, so this
+// row's parity is UNPINNED): source coordinate (d + 0.5) * scale - 0.5, 11-bit coefficients, horizontal pass in
+// int32, vertical pass ((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2.
+// =============================================================================================
+__device__ __forceinline__ void lin_coef(int d, int dst, int src, int* s0, int* s1, int* c0, int* c1) {
+  const double scale = (double)src / (double)dst;
+  float f = (float)(((double)d + 0.5) * scale - 0.5);
+  int i = (int)floorf(f);
+  f -= (float)i;
+  if (i < 0) {
+    i = 0;
+    f = 0.f;
+  }
+  if (i >= src - 1) {
+    i = src - 1;
+    f = 0.f;
+  }
+  *s0 = i;
+  *s1 = min(i + 1, src - 1);
+  const float k0 = (1.f - f) * 2048.f, k1 = f * 2048.f;
+  *c0 = (int)rintf(k0);
+  *c1 = (int)rintf(k1);
+}
+
+__global__ __launch_bounds__(256) void preprocess_u8_k(const unsigned char* __restrict__ frames, int hs, int ws,
+                                                       const unsigned char* __restrict__ labels, int h, int w, int gray,
+                                                       float m0, float m1, float m2, float i0, float i1, float i2,
+                                                       float* __restrict__ x, long long* __restrict__ y) {
+  const int n = blockIdx.y;
+  const int px = blockIdx.x * 256 + threadIdx.x;
+  if (px >= h * w) return;
+  const int dy = px / w, dx = px - dy * w;
+  int x0, x1, a0, a1, y0, y1, b0, b1;
+  lin_coef(dx, w, ws, &x0, &x1, &a0, &a1);
+  lin_coef(dy, h, hs, &y0, &y1, &b0, &b1);
+  const unsigned char* f = frames + (long long)n * hs * ws * 3;
+  int v[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int r0 = f[((long long)y0 * ws + x0) * 3 + c] * a0 + f[((long long)y0 * ws + x1) * 3 + c] * a1;
+    const int r1 = f[((long long)y1 * ws + x0) * 3 + c] * a0 + f[((long long)y1 * ws + x1) * 3 + c] * a1;
+    int o = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+    v[c] = min(max(o, 0), 255);
+  }
+  if (gray) {  // ToGray: cv2 RGB2GRAY fixed point on the stored channel order, replicated to 3 channels
+    const int g = (v[0] * 4899 + v[1] * 9617 + v[2] * 1868 + (1 << 13)) >> 14;
+    v[0] = v[1] = v[2] = g;
+  }
+  const long long hw = (long long)h * w;
+  float* xo = x + (long long)n * 3 * hw + px;
+  xo[0] = ((float)v[0] - m0) * i0;  // Normalize: (img - mean*255) * (1 / (std*255)), float32
+  xo[hw] = ((float)v[1] - m1) * i1;
+  xo[2 * hw] = ((float)v[2] - m2) * i2;
+  if (labels != nullptr && y != nullptr) {  // cv2 INTER_NEAREST: floor(d * scale)
+    const int sy = min((int)floor((double)dy * ((double)hs / (double)h)), hs - 1);
+    const int sx = min((int)floor((double)dx * ((double)ws / (double)w)), ws - 1);
+    y[(long long)n * hw + px] = (long long)labels[((long long)n * hs + sy) * ws + sx];
+  }
+}
+
+int preprocess_u8(const unsigned char* frames, int N, int hs, int ws, const unsigned char* labels, int h, int w, int gray,
+                  const float* mean3, const float* std3, float* x, long long* y, hipStream_t s) {
+  const float m0 = mean3[0] * 255.f, m1 = mean3[1] * 255.f, m2 = mean3[2] * 255.f;
+  const float i0 = 1.f / (std3[0] * 255.f), i1 = 1.f / (std3[1] * 255.f), i2 = 1.f / (std3[2] * 255.f);
+  dim3 grid((unsigned)((h * w + 255) / 256), (unsigned)N);
+  hipLaunchKernelGGL(preprocess_u8_k, grid, dim3(256), 0, s, frames, hs, ws, labels, h, w, gray, m0, m1, m2, i0, i1, i2,
+                     x, y);
+  RLN_LAUNCH_CHECK();
+}
+
+// =============================================================================================
 // EncDecNet pieces
 // =============================================================================================
 
