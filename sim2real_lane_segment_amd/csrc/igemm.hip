@@ -1161,6 +1161,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_k(const WgradParams p) {
   constexpr int NVP = (C::VCH / VG) * VSUB;           // V loads per thread
   static_assert(UPIX == 128 && C::UCH % UG == 0 && C::VCH % VG == 0, "staging map assumes 128-pixel tiles");
   float ru[NUP], rv[NVP];
+  // partial channel groups: V channels past Vc are neither loaded nor committed (their LDS rows only feed output
+  // rows/columns that are never stored), and waves whose 16 N-side channels are all past the end skip their MFMAs
+  // (guarding single M-tiles inside the unrolled MFMA stream measured slower than computing the padding)
+  const int nvalid_v = min(C::VCH, p.Vc - vbase);                      // >= 1
+  const int nvalid_u = min(C::UCH, p.Uc - ubase);                      // >= 1
+  const int n_live = SHIFT_A ? nvalid_u : nvalid_v;                    // N side: one 16-channel tile per wave
+  const bool wave_live = wave * 16 < n_live;
 
   f32x4 acc[MT][C::NS];
 #pragma unroll
@@ -1243,8 +1250,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_k(const WgradParams p) {
       bits |= (ok ? 1u : 0u) << (1 + k);
       const int voff = vsafe * p.v_cs + (ok ? iy * p.Wv + ix : 0);
 #pragma unroll
-      for (int i = 0; i < C::VCH / VG; ++i)
+      for (int i = 0; i < C::VCH / VG; ++i) {
+        if (i * VG >= nvalid_v) break;  // uniform
         rv[i * VSUB + k] = vn[voff + (min(vbase + i * VG, cvmax) - vb0) * p.v_cs];  // uniform 32-bit channel offset
+      }
     }
     okbits = bits;
   };
@@ -1268,6 +1277,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_k(const WgradParams p) {
             for (int j = 0; j < GRP; ++j) ab[j] = *reinterpret_cast<const float2*>(abl + 2 * ((g + j) * VG + v_sub));
 #pragma unroll
             for (int j = 0; j < GRP; ++j) {
+              if ((g + j) * VG >= nvalid_v) break;  // uniform
               const int c = (g + j) * VG + v_sub;
               const float z = fmaxf(fmaf(ab[j].x, rv[(g + j) * VSUB + k], ab[j].y), 0.f);
               vl[c * C::VST + v_pos[k]] = z * vmul;
@@ -1276,6 +1286,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_k(const WgradParams p) {
         } else {
 #pragma unroll
           for (int i = 0; i < NI; ++i) {
+            if (i * VG >= nvalid_v) break;  // uniform
             const int c = i * VG + v_sub;
             vl[c * C::VST + v_pos[k]] = (vmul != 0.f && vbase + c < p.Vc) ? rv[i * VSUB + k] : 0.f;
           }
@@ -1315,7 +1326,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_k(const WgradParams p) {
     if (it + 1 < it1) issue(it + 1);
     stamp(t_issue);
     // ---- MFMA over the tile's pixels, 4 consecutive x per k-step; straight-line, constexpr LDS offsets ----
-    {
+    if (wave_live) {
       const float* ubase = ul + lj * C::UST + lk;
       const float* vbase = vl + lj * C::VST + lk;
       const float* uw = ubase + (SHIFT_A ? wave * 16 * C::UST : 0);
