@@ -422,9 +422,11 @@ void level_dims(const rln_ctx* c, int h, int w, std::vector<int>& hs, std::vecto
 // input-channel loop is split over blocks.  The factor depends on the level's pixel count ONLY (not on the batch
 // size), so a sample's result does not depend on which batch it is evaluated in.
 int dense_fwd_split(int hw, int cin) {
-  if (hw > 512 || hw <= 0 || getenv("RLN_NO_SPLITK")) return 1;
+  static const int mid = getenv("RLN_SPLIT_MID") ? atoi(getenv("RLN_SPLIT_MID")) : 2;  // 512 < hw <= 1200 (measured: 2)
+  if (hw > 1200 || hw <= 0 || getenv("RLN_NO_SPLITK")) return 1;
+  if (hw > 512 && mid <= 1) return 1;
   const int nchunk = (cin + 15) / 16;
-  const int want = hw <= 128 ? 8 : 4;
+  const int want = hw <= 128 ? 8 : (hw <= 512 ? 4 : mid);
   return std::max(1, std::min(want, nchunk));
 }
 
