@@ -114,5 +114,6 @@ int wgrad_launch(WgradKind kind, int tile, const WgradParams& p, hipStream_t str
 void wgrad_tile_dims(WgradKind kind, int tile, int* th, int* tw);
 int wgrad_pick_tile(int gh, int gw);
 void wgrad_block_dims(WgradKind kind, int* m_per_block, int* n_per_block);
+int wgrad_dense_q_channels(const WgradParams& p);  // 0 / 32 / 64: V channels per block the dense launch will use
 
 }  // namespace rln

@@ -1394,7 +1394,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_k(const WgradParams p) {
 // Same contraction and partial-slab contract as wgrad_k<3,1,PRO_BNRELU,false>, but the V image is aligned in x
 // (it starts 4 columns left of the tile and is TW+8 wide) so that global loads are dwordx4 (17 per thread and
 // item instead of 72 dword loads) and LDS commits are ds_write_b64.
-template <int TH, int TW>
+template <int TH, int TW, int NCH_>
 struct WgqCfg {
   static constexpr int QW = TW / 4 + 2;       // quads per image row
   static constexpr int ROWS = TH + 2;
@@ -1403,26 +1403,33 @@ struct WgqCfg {
   static constexpr int QPC = ROWS * QW;       // quads per channel
   static constexpr int VST = round_mod32(POS, 2);
   static constexpr int UST = round_mod32(TH * TW, 2);
-  static constexpr int NCH = 64, MCH = 16;
-  static constexpr int NQV = NCH * QPC / 256;
+  static constexpr int NCH = NCH_, MCH = 16;  // V channels per block (64: one N-tile per wave; 32: waves also split rows)
+  static constexpr int NTW = NCH / 16;        // N-tiles
+  static constexpr int PSPLIT = 4 / NTW;      // row groups of the tile shared out over the waves
+  static constexpr int VQ = NCH * QPC;        // V quads per item
+  static constexpr int NQV = cdiv(VQ, 256);
   static constexpr int NQU = MCH * (TH * TW / 4) / 256;
+  static constexpr int GRP = (NQV % 5 == 0) ? 5 : 4;
   static constexpr int V_FLOATS = NCH * VST;
   static constexpr int U_FLOATS = MCH * UST;
   static constexpr int LDS_BYTES = (V_FLOATS + U_FLOATS + 2 * NCH) * 4;
-  static_assert((NCH * QPC) % 256 == 0 && (MCH * TH * TW / 4) % 256 == 0, "whole passes");
-  static_assert(TH * TW == 128 && VST % 2 == 0 && UST % 2 == 0, "128-pixel tiles, 8-byte aligned LDS rows");
+  static constexpr int BLOCKS_PER_CU = (NCH == 64) ? 2 : 3;
+  static_assert((MCH * TH * TW / 4) % 256 == 0 && NQV % GRP == 0, "whole passes / groups");
+  static_assert(TH * TW == 128 && VST % 2 == 0 && UST % 2 == 0 && TH % PSPLIT == 0, "128-pixel tiles, 8-byte LDS rows");
+  static_assert(PSPLIT == 1 || 2 * 9 * 4 * 64 <= V_FLOATS, "row-group reduction reuses the V image");
   __host__ __device__ static constexpr int slot_off(int s) { return (s / 3) * PITCH + (s % 3) + 3; }
 };
 
-template <int TH, int TW>
-__global__ __launch_bounds__(256, 2) void wgrad_dense_q_k(const WgradParams p) {
-  using C = WgqCfg<TH, TW>;
+template <int TH, int TW, int NCH_>
+__global__ __launch_bounds__(256, (NCH_ == 64 ? 2 : 3)) void wgrad_dense_q_k(const WgradParams p) {
+  using C = WgqCfg<TH, TW, NCH_>;
   extern __shared__ __align__(16) float smem[];
   float* vl = smem;
   float* ul = smem + C::V_FLOATS;
   float* abl = ul + C::U_FLOATS;  // [NCH][2]
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6, lj = lane & 15, lk = lane >> 4;
+  const int ntile = wave % C::NTW, ph = wave / C::NTW;  // this wave's N-tile and row group
   const int chunk = blockIdx.x;
   const int nbase = blockIdx.z * C::NCH;  // V (conv input) channels of this block; U = all 16 dY channels
 
@@ -1437,7 +1444,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dense_q_k(const WgradParams p) {
   int vgo[C::NQV], vmeta[C::NQV];  // global offset relative to (sample, tile origin) ; lds | r << 20 | q << 24
 #pragma unroll
   for (int i = 0; i < C::NQV; ++i) {
-    const int e = tid + 256 * i;
+    const int e = min(tid + 256 * i, C::VQ - 1);  // a partial last pass repeats the last quad (same value, same slot)
     const int ch = e / C::QPC, rem = e - ch * C::QPC;
     const int r = rem / C::QW, q = rem - r * C::QW;
     const int cg = min(nbase + ch, p.Vc - 1) - min(nbase, p.Vc - 1);
@@ -1456,12 +1463,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_dense_q_k(const WgradParams p) {
   }
   float4 rv[C::NQV], ru[C::NQU];
   unsigned okv = 0, oku = 0;
-  // Partial last channel group (Vc % 64 != 0): staging passes that hold only channels >= Vc are skipped, and so is
-  // the MFMA phase of waves whose 16 channels are all >= Vc (their LDS rows are then never read).  Over the
-  // layers of FCDenseNet67 14 % of the 64-channel slots are such padding.
+  // Partial last channel group (Vc % NCH != 0): staging passes that hold only channels >= Vc are skipped, and so is
+  // the MFMA phase of waves whose 16 channels are all >= Vc (their LDS rows are then never read).
   const int nvalid = min(C::NCH, p.Vc - nbase);                       // >= 1
   const int nqv = min(C::NQV, (nvalid * C::QPC + 255) / 256);         // passes that touch a valid channel
-  const bool wave_live = wave * 16 < nvalid;
+  const bool wave_live = ntile * 16 < nvalid;
 
   f32x4 acc[C::MCH / 16][9];
 #pragma unroll
@@ -1512,14 +1518,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_dense_q_k(const WgradParams p) {
       *reinterpret_cast<float2*>(d) = make_float2(ok ? ru[i].x : 0.f, ok ? ru[i].y : 0.f);
       *reinterpret_cast<float2*>(d + 2) = make_float2(ok ? ru[i].z : 0.f, ok ? ru[i].w : 0.f);
     }
-    constexpr int GRP = 5;
-    static_assert(C::NQV % GRP == 0, "quad groups");
+    constexpr int GRP = C::GRP;
 #pragma unroll
     for (int g = 0; g < C::NQV; g += GRP) {
       float2 ab[GRP];
 #pragma unroll
       for (int j = 0; j < GRP; ++j) {
-        const int ch = (tid + 256 * (g + j)) / C::QPC;
+        const int ch = min(tid + 256 * (g + j), C::VQ - 1) / C::QPC;
         ab[j] = *reinterpret_cast<const float2*>(abl + 2 * ch);
       }
 #pragma unroll
@@ -1545,10 +1550,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_dense_q_k(const WgradParams p) {
     if (it + 1 < it1) issue(it + 1);
     if (wave_live) {
       const float* uw = ul + lj * C::UST + lk;
-      const float* vw = vl + (wave * 16 + lj) * C::VST + lk;
+      const float* vw = vl + (ntile * 16 + lj) * C::VST + lk;
       constexpr int KPR = TW / 4;
+      constexpr int RPW = TH / C::PSPLIT;  // tile rows per wave
 #pragma unroll 1
-      for (int ty = 0; ty < TH; ++ty) {
+      for (int ty = ph * RPW; ty < (ph + 1) * RPW; ++ty) {
         const float* ur = uw + ty * TW;
         const float* vr = vw + ty * C::PITCH;
 #pragma unroll 2
@@ -1562,22 +1568,41 @@ __global__ __launch_bounds__(256, 2) void wgrad_dense_q_k(const WgradParams p) {
     }
   }
 
-  float* dst = p.partial + (long long)chunk * p.wsize;
-  const int nch = nbase + wave * 16 + lj;
+  if constexpr (C::PSPLIT == 2) {  // add the second row group's sums to the first (fixed order)
+    __syncthreads();               // the V image is free
+    float* rs = vl + ntile * (9 * 4 * 64);
+    if (ph == 1) {
 #pragma unroll
-  for (int s = 0; s < 9; ++s)
+      for (int s = 0; s < 9; ++s)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int mch = 4 * lk + r;
-      if (mch < p.Uc && nch < p.Vc) dst[(long long)mch * p.m_stride + (long long)nch * p.n_stride + s] = acc[0][s][r];
+        for (int r = 0; r < 4; ++r) rs[(s * 4 + r) * 64 + lane] = acc[0][s][r];
     }
+    __syncthreads();
+    if (ph == 0) {
+#pragma unroll
+      for (int s = 0; s < 9; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[0][s][r] += rs[(s * 4 + r) * 64 + lane];
+    }
+  }
+  if (ph == 0) {
+    float* dst = p.partial + (long long)chunk * p.wsize;
+    const int nch = nbase + ntile * 16 + lj;
+#pragma unroll
+    for (int s = 0; s < 9; ++s)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mch = 4 * lk + r;
+        if (mch < p.Uc && nch < p.Vc) dst[(long long)mch * p.m_stride + (long long)nch * p.n_stride + s] = acc[0][s][r];
+      }
+  }
 }
 
-template <int TH, int TW>
+template <int TH, int TW, int NCH_>
 static int wlaunch_q(const WgradParams& p, hipStream_t stream) {
-  using C = WgqCfg<TH, TW>;
+  using C = WgqCfg<TH, TW, NCH_>;
   static bool attr_done = false;
-  auto kern = wgrad_dense_q_k<TH, TW>;
+  auto kern = wgrad_dense_q_k<TH, TW, NCH_>;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               C::LDS_BYTES);
@@ -1586,10 +1611,10 @@ static int wlaunch_q(const WgradParams& p, hipStream_t stream) {
     if (getenv("RLN_DEBUG_OCC")) {
       int nb = -1;
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 256, C::LDS_BYTES);
-      fprintf(stderr, "[rln] wgrad_dense_q_k<%dx%d> lds %d B -> %d blocks/CU\n", TH, TW, C::LDS_BYTES, nb);
+      fprintf(stderr, "[rln] wgrad_dense_q_k<%dx%d,%d> lds %d B -> %d blocks/CU\n", TH, TW, NCH_, C::LDS_BYTES, nb);
     }
   }
-  dim3 grid((unsigned)p.nchunks, 1u, (unsigned)((p.Vc + 63) / 64));
+  dim3 grid((unsigned)p.nchunks, 1u, (unsigned)((p.Vc + NCH_ - 1) / NCH_));
   hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, stream, p);
   return (int)hipGetLastError();
 }
@@ -1648,14 +1673,22 @@ void wgrad_block_dims(WgradKind kind, int* m_per_block, int* n_per_block) {
   *n_per_block = 64;
 }
 
+// V channels per block of the 16-byte staging kernel the dense launch will use (0: generic kernel, 64 per block)
+int wgrad_dense_q_channels(const WgradParams& p) {
+  static const bool noq = getenv("RLN_NO_WGQ") != nullptr;
+  static const int nch = getenv("RLN_WGQ_NCH") ? atoi(getenv("RLN_WGQ_NCH")) : 32;
+  const bool al = ((reinterpret_cast<uintptr_t>(p.u) | reinterpret_cast<uintptr_t>(p.v)) & 15) == 0;
+  const bool q = !noq && al && p.Uc <= 16 && (p.GW % 4) == 0 && p.Wv == p.GW && p.Hv == p.GH &&
+                 (p.u_cs % 4) == 0 && (p.v_cs % 4) == 0 && (p.u_ns % 4) == 0 && (p.v_ns % 4) == 0;
+  return q ? (nch == 64 ? 64 : 32) : 0;
+}
+
 int wgrad_launch(WgradKind kind, int tile, const WgradParams& p, hipStream_t stream) {
   switch (kind) {
     case WG_DENSE3: {
-      static const bool noq = getenv("RLN_NO_WGQ") != nullptr;
-      const bool al = ((reinterpret_cast<uintptr_t>(p.u) | reinterpret_cast<uintptr_t>(p.v)) & 15) == 0;
-      const bool q = !noq && al && p.Uc <= 16 && (p.GW % 4) == 0 && p.Wv == p.GW && p.Hv == p.GH &&
-                     (p.u_cs % 4) == 0 && (p.v_cs % 4) == 0 && (p.u_ns % 4) == 0 && (p.v_ns % 4) == 0;
-      if (q) return tile == 0 ? wlaunch_q<4, 32>(p, stream) : wlaunch_q<8, 16>(p, stream);
+      const int nch = wgrad_dense_q_channels(p);
+      if (nch == 32) return tile == 0 ? wlaunch_q<4, 32, 32>(p, stream) : wlaunch_q<8, 16, 32>(p, stream);
+      if (nch == 64) return tile == 0 ? wlaunch_q<4, 32, 64>(p, stream) : wlaunch_q<8, 16, 64>(p, stream);
       return tile == 0 ? wlaunch_t<3, 1, PRO_BNRELU, false, 4, 32>(p, stream)
                        : wlaunch_t<3, 1, PRO_BNRELU, false, 8, 16>(p, stream);
     }

@@ -430,8 +430,8 @@ int dense_fwd_split(int hw, int cin) {
   return std::max(1, std::min(want, nchunk));
 }
 
-long long wgrad_chunks(long long total_items, int mgroups, int ngroups, int* ipc) {
-  long long want = (1024 + (long long)mgroups * ngroups - 1) / ((long long)mgroups * ngroups);
+long long wgrad_chunks(long long total_items, int mgroups, int ngroups, int* ipc, int want_blocks = 1024) {
+  long long want = (want_blocks + (long long)mgroups * ngroups - 1) / ((long long)mgroups * ngroups);
   if (want < 1) want = 1;
   if (want > total_items) want = total_items;
   long long per = (total_items + want - 1) / want;
@@ -481,7 +481,9 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
         int wth, wtw, ipc;
         wgrad_tile_dims(WG_DENSE3, wgrad_pick_tile(Hd, Wd), &wth, &wtw);
         const long long items = (long long)n * ((Hd + wth - 1) / wth) * ((Wd + wtw - 1) / wtw);
-        const long long nch = wgrad_chunks(items, (o.cout + 15) / 16, (o.cin + 63) / 64, &ipc);
+        // both block shapes of the dense weight gradient (64 V channels / ~1024 blocks, 32 / ~1536 blocks)
+        const long long nch = std::max(wgrad_chunks(items, (o.cout + 15) / 16, (o.cin + 63) / 64, &ipc),
+                                       wgrad_chunks(items, (o.cout + 15) / 16, (o.cin + 31) / 32, &ipc, 1536));
         wp_max = std::max(wp_max, (size_t)nch * o.cout * o.cin * 9);
       }
     } else if (o.type == OP_TD) {
@@ -807,12 +809,17 @@ int run_wgrad(rln_ctx* c, WgradKind kind, WgradParams& w, int Mc, int Nc, int64_
   int th, tw, mpb, npb;
   wgrad_tile_dims(kind, tile, &th, &tw);
   wgrad_block_dims(kind, &mpb, &npb);
+  int want_blocks = 1024;
+  if (kind == WG_DENSE3 && wgrad_dense_q_channels(w) == 32) {  // 32-channel blocks, three per CU
+    npb = 32;
+    want_blocks = 1536;
+  }
   w.tiles_y = (w.GH + th - 1) / th;
   w.tiles_x = (w.GW + tw - 1) / tw;
   w.N = c->N;
   const long long items = (long long)c->N * w.tiles_x * w.tiles_y;
   int ipc;
-  const long long nch = wgrad_chunks(items, (Mc + mpb - 1) / mpb, (Nc + npb - 1) / npb, &ipc);
+  const long long nch = wgrad_chunks(items, (Mc + mpb - 1) / mpb, (Nc + npb - 1) / npb, &ipc, want_blocks);
   w.items_per_chunk = ipc;
   w.nchunks = (int)nch;
   w.partial = c->wpartial;
