@@ -114,7 +114,8 @@ __device__ __forceinline__ void igemm_compute_convt4(const float* __restrict__ z
 // CLS: 0 plain convolution; 1 ConvTranspose2d forward, one output-parity class per block (grid.x = 4 * tiles);
 //      2 ConvTranspose2d forward, all four classes per block (NT = 1)
 template <int KS, int NT, int PRO, int EPI, int TH, int TW, int CLS, bool V4>
-__global__ __launch_bounds__(256, ((NT == 1 && TH * TW <= 256 && CLS != 2) ? 4 : ((NT == 1 && TH * TW <= 320) ? 3 : 2)))
+__global__ __launch_bounds__(256, (((NT == 1 && TH * TW <= 256 && CLS != 2) || (KS == 1 && EPI == EPI_POOL)) ? 4
+                                   : ((NT == 1 && TH * TW <= 320) ? 3 : 2)))
     void igemm_k(const IgemmParams p) {
   using C = IgCfg<KS, NT, PRO, EPI, TH, TW, V4>;
   static_assert(!V4 || (PRO != PRO_S2D && C::CHS % 4 == 0 && C::PITCH % 4 == 0), "V4 needs 16-byte aligned LDS rows");
@@ -1412,16 +1413,16 @@ struct WgqCfg {
   static constexpr int GRP = (NQV % 5 == 0) ? 5 : 4;
   static constexpr int V_FLOATS = NCH * VST;
   static constexpr int U_FLOATS = MCH * UST;
-  static constexpr int LDS_BYTES = (V_FLOATS + U_FLOATS + 2 * NCH) * 4;
-  static constexpr int BLOCKS_PER_CU = (NCH == 64) ? 2 : 3;
+  static constexpr int RED_FLOATS = (PSPLIT - 1) * NTW * 9 * 4 * 64;  // row-group reduction (reuses the staging area)
+  static constexpr int LDS_BYTES = cmax(V_FLOATS + U_FLOATS + 2 * NCH, RED_FLOATS) * 4;
+  static constexpr int BLOCKS_PER_CU = (NCH == 64) ? 2 : (NCH == 32 ? 3 : 4);
   static_assert((MCH * TH * TW / 4) % 256 == 0 && NQV % GRP == 0, "whole passes / groups");
   static_assert(TH * TW == 128 && VST % 2 == 0 && UST % 2 == 0 && TH % PSPLIT == 0, "128-pixel tiles, 8-byte LDS rows");
-  static_assert(PSPLIT == 1 || 2 * 9 * 4 * 64 <= V_FLOATS, "row-group reduction reuses the V image");
   __host__ __device__ static constexpr int slot_off(int s) { return (s / 3) * PITCH + (s % 3) + 3; }
 };
 
 template <int TH, int TW, int NCH_>
-__global__ __launch_bounds__(256, (NCH_ == 64 ? 2 : 3)) void wgrad_dense_q_k(const WgradParams p) {
+__global__ __launch_bounds__(256, (NCH_ == 64 ? 2 : (NCH_ == 32 ? 3 : 4))) void wgrad_dense_q_k(const WgradParams p) {
   using C = WgqCfg<TH, TW, NCH_>;
   extern __shared__ __align__(16) float smem[];
   float* vl = smem;
@@ -1568,10 +1569,10 @@ __global__ __launch_bounds__(256, (NCH_ == 64 ? 2 : 3)) void wgrad_dense_q_k(con
     }
   }
 
-  if constexpr (C::PSPLIT == 2) {  // add the second row group's sums to the first (fixed order)
-    __syncthreads();               // the V image is free
-    float* rs = vl + ntile * (9 * 4 * 64);
-    if (ph == 1) {
+  if constexpr (C::PSPLIT > 1) {  // add the other row groups' sums to the first (fixed order)
+    __syncthreads();              // the staging area is free
+    if (ph > 0) {
+      float* rs = smem + ((ph - 1) * C::NTW + ntile) * (9 * 4 * 64);
 #pragma unroll
       for (int s = 0; s < 9; ++s)
 #pragma unroll
@@ -1580,9 +1581,13 @@ __global__ __launch_bounds__(256, (NCH_ == 64 ? 2 : 3)) void wgrad_dense_q_k(con
     __syncthreads();
     if (ph == 0) {
 #pragma unroll
-      for (int s = 0; s < 9; ++s)
+      for (int g = 0; g < C::PSPLIT - 1; ++g) {
+        const float* rs = smem + (g * C::NTW + ntile) * (9 * 4 * 64);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[0][s][r] += rs[(s * 4 + r) * 64 + lane];
+        for (int s = 0; s < 9; ++s)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[0][s][r] += rs[(s * 4 + r) * 64 + lane];
+      }
     }
   }
   if (ph == 0) {
@@ -1680,13 +1685,14 @@ int wgrad_dense_q_channels(const WgradParams& p) {
   const bool al = ((reinterpret_cast<uintptr_t>(p.u) | reinterpret_cast<uintptr_t>(p.v)) & 15) == 0;
   const bool q = !noq && al && p.Uc <= 16 && (p.GW % 4) == 0 && p.Wv == p.GW && p.Hv == p.GH &&
                  (p.u_cs % 4) == 0 && (p.v_cs % 4) == 0 && (p.u_ns % 4) == 0 && (p.v_ns % 4) == 0;
-  return q ? (nch == 64 ? 64 : 32) : 0;
+  return q ? (nch == 64 ? 64 : (nch == 16 ? 16 : 32)) : 0;
 }
 
 int wgrad_launch(WgradKind kind, int tile, const WgradParams& p, hipStream_t stream) {
   switch (kind) {
     case WG_DENSE3: {
       const int nch = wgrad_dense_q_channels(p);
+      if (nch == 16) return tile == 0 ? wlaunch_q<4, 32, 16>(p, stream) : wlaunch_q<8, 16, 16>(p, stream);
       if (nch == 32) return tile == 0 ? wlaunch_q<4, 32, 32>(p, stream) : wlaunch_q<8, 16, 32>(p, stream);
       if (nch == 64) return tile == 0 ? wlaunch_q<4, 32, 64>(p, stream) : wlaunch_q<8, 16, 64>(p, stream);
       return tile == 0 ? wlaunch_t<3, 1, PRO_BNRELU, false, 4, 32>(p, stream)

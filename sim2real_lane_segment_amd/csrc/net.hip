@@ -482,8 +482,9 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
         wgrad_tile_dims(WG_DENSE3, wgrad_pick_tile(Hd, Wd), &wth, &wtw);
         const long long items = (long long)n * ((Hd + wth - 1) / wth) * ((Wd + wtw - 1) / wtw);
         // both block shapes of the dense weight gradient (64 V channels / ~1024 blocks, 32 / ~1536 blocks)
-        const long long nch = std::max(wgrad_chunks(items, (o.cout + 15) / 16, (o.cin + 63) / 64, &ipc),
-                                       wgrad_chunks(items, (o.cout + 15) / 16, (o.cin + 31) / 32, &ipc, 1536));
+        const long long nch = std::max({wgrad_chunks(items, (o.cout + 15) / 16, (o.cin + 63) / 64, &ipc),
+                                        wgrad_chunks(items, (o.cout + 15) / 16, (o.cin + 31) / 32, &ipc, 1536),
+                                        wgrad_chunks(items, (o.cout + 15) / 16, (o.cin + 15) / 16, &ipc, 2048)});
         wp_max = std::max(wp_max, (size_t)nch * o.cout * o.cin * 9);
       }
     } else if (o.type == OP_TD) {
@@ -813,6 +814,9 @@ int run_wgrad(rln_ctx* c, WgradKind kind, WgradParams& w, int Mc, int Nc, int64_
   if (kind == WG_DENSE3 && wgrad_dense_q_channels(w) == 32) {  // 32-channel blocks, three per CU
     npb = 32;
     want_blocks = 1536;
+  } else if (kind == WG_DENSE3 && wgrad_dense_q_channels(w) == 16) {
+    npb = 16;
+    want_blocks = 2048;
   }
   w.tiles_y = (w.GH + th - 1) / th;
   w.tiles_x = (w.GW + tw - 1) / tw;
