@@ -146,24 +146,35 @@ class FCDenseNet(nn.Module, EngineOwner):
         return probs
 
 
+# The named variants of the reference (tiramisu.py:150-194): layers per down block, per up block, bottleneck, growth.
+# All of them start with a 48-channel first convolution on 3 input channels.
+_VARIANTS = {
+    "57": ((4,) * 5, (4,) * 5, 4, 12),
+    "67": ((5,) * 5, (5,) * 5, 5, 16),
+    "103": ((4, 5, 7, 10, 12), (12, 10, 7, 5, 4), 15, 16),
+}
+
+
+def _variant(name):
+    down, up, bottleneck, growth = _VARIANTS[name]
+    return dict(in_channels=3, down_blocks=down, up_blocks=up, bottleneck_layers=bottleneck, growth_rate=growth,
+                out_chans_first_conv=48)
+
+
 def FCDenseNet57(n_classes, kernel_size=1):
-    return FCDenseNet(in_channels=3, down_blocks=(4, 4, 4, 4, 4), up_blocks=(4, 4, 4, 4, 4), bottleneck_layers=4,
-                      growth_rate=12, out_chans_first_conv=48, n_classes=n_classes, kernel_size=kernel_size)
+    return FCDenseNet(n_classes=n_classes, kernel_size=kernel_size, **_variant("57"))
 
 
 def FCDenseNet67(n_classes):
-    return FCDenseNet(in_channels=3, down_blocks=(5, 5, 5, 5, 5), up_blocks=(5, 5, 5, 5, 5), bottleneck_layers=5,
-                      growth_rate=16, out_chans_first_conv=48, n_classes=n_classes)
+    return FCDenseNet(n_classes=n_classes, **_variant("67"))
 
 
 def FCDenseNet103(n_classes):
-    return FCDenseNet(in_channels=3, down_blocks=(4, 5, 7, 10, 12), up_blocks=(12, 10, 7, 5, 4), bottleneck_layers=15,
-                      growth_rate=16, out_chans_first_conv=48, n_classes=n_classes)
+    return FCDenseNet(n_classes=n_classes, **_variant("103"))
 
 
 def FCDenseNet57Base():
-    return FCDenseNetFeatureExtractor(in_channels=3, down_blocks=(4, 4, 4, 4, 4), up_blocks=(4, 4, 4, 4, 4),
-                                      bottleneck_layers=4, growth_rate=12, out_chans_first_conv=48)
+    return FCDenseNetFeatureExtractor(**_variant("57"))
 
 
 def FCDenseNet57Classifier(n_classes):
@@ -171,8 +182,7 @@ def FCDenseNet57Classifier(n_classes):
 
 
 def FCDenseNet67Base():
-    return FCDenseNetFeatureExtractor(in_channels=3, down_blocks=(5, 5, 5, 5, 5), up_blocks=(5, 5, 5, 5, 5),
-                                      bottleneck_layers=5, growth_rate=16, out_chans_first_conv=48)
+    return FCDenseNetFeatureExtractor(**_variant("67"))
 
 
 def FCDenseNet67Classifier(n_classes):
