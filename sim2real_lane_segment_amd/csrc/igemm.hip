@@ -478,8 +478,62 @@ __global__ __launch_bounds__(256, (((NT == 1 && TH * TW <= 256 && CLS != 2) || (
         }
         accum = (j >= p.acc_lo) && (j < p.acc_hi);
       }
+      bool dgrad_done = false;
+      if constexpr (EPI == EPI_DGRAD) {
+        if (p.out_vec) {
+          // 16-byte form: the S / G quads of all pixel groups of this channel tile are loaded TOGETHER (one latency
+          // instead of MPW), from clamped always-valid addresses through an opaque pointer (as a plain branch the
+          // compiler folds this path into the scalar one), then masked, accumulated and stored.
+          const int jc = min(j, p.J - 1);
+          const float* sbase = p.S + (long long)n * p.s_ns + (long long)jc * p.out_cs;
+          float* gbase = p.out + (long long)n * p.out_ns + (long long)jc * p.out_cs;
+          asm volatile("" : "+v"(sbase), "+v"(gbase));
+          float4 s4[MPW], g4[MPW];
+          int poff[MPW];
+          bool okm[MPW];
+#pragma unroll
+          for (int m = 0; m < MPW; ++m) {
+            const int q = (wave * MPW + m) * 16 + lk * 4;
+            const int ty = q / TW, tx = q - ty * TW;
+            const int gy = gy0 + ty, gx = gx0 + tx;
+            okm[m] = jv && gy < p.GH && gx < p.GW;  // W % 4 == 0: a 4-pixel group is all-in or all-out
+            poff[m] = okm[m] ? gy * p.GW + gx : 0;
+            s4[m] = *reinterpret_cast<const float4*>(sbase + poff[m]);
+          }
+          if (accum) {
+#pragma unroll
+            for (int m = 0; m < MPW; ++m) g4[m] = *reinterpret_cast<const float4*>(gbase + poff[m]);
+          } else {
+#pragma unroll
+            for (int m = 0; m < MPW; ++m) g4[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+          float ovv[MPW][4];
+#pragma unroll
+          for (int m = 0; m < MPW; ++m) {
+            const float sv[4] = {s4[m].x, s4[m].y, s4[m].z, s4[m].w};
+            const float gv[4] = {g4[m].x, g4[m].y, g4[m].z, g4[m].w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float yv = fmaf(ea, sv[r], eb);
+              const float gyv = (okm[m] && yv > 0.f) ? acc[m][nt][r] : 0.f;
+              const float xh = (sv[r] - emean) * einv;
+              s1 += gyv;
+              s2 += gyv * xh;
+              ovv[m][r] = fmaf(egam, gyv, gv[r]);
+            }
+          }
+#pragma unroll
+          for (int m = 0; m < MPW; ++m)
+            asm volatile("" ::"v"(ovv[m][0]), "v"(ovv[m][1]), "v"(ovv[m][2]), "v"(ovv[m][3]) : "memory");
+#pragma unroll
+          for (int m = 0; m < MPW; ++m)
+            if (okm[m]) *reinterpret_cast<float4*>(gbase + poff[m]) = make_float4(ovv[m][0], ovv[m][1], ovv[m][2], ovv[m][3]);
+          dgrad_done = true;
+        }
+      }
 #pragma unroll
       for (int cl = 0; cl < NCL; ++cl) {  // output-parity classes held by this block (1 unless CLS == 2)
+        if (dgrad_done) break;
         const int pyc = (CLS == 2) ? (cl >> 1) : py, pxc = (CLS == 2) ? (cl & 1) : px;
         f32x4(&accc)[MPW][NT] = accs[cl];
   #pragma unroll
