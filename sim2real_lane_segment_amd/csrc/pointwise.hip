@@ -752,7 +752,7 @@ __global__ __launch_bounds__(256) void head_bwd_fused_k(const HeadBwdParams q, f
     float ss = 0.f, d[NC];
 #pragma unroll
     for (int k = 0; k < NC; ++k) d[k] = 0.f;
-#pragma unroll 4
+#pragma unroll 18
     for (int c = g; c < p.C; c += 8) {
       const float x = Sn[(long long)c * p.HW + pxs];
       xs[c * HEAD_XS + pl] = x;
@@ -818,7 +818,7 @@ __global__ __launch_bounds__(256) void head_bwd_fused_k(const HeadBwdParams q, f
       }
     }
     // ---- (2) feature gradient of this thread's channels ----
-#pragma unroll 4
+#pragma unroll 18
     for (int c = g; c < p.C; c += 8) {
       const float x = xs[c * HEAD_XS + pl];
       float gxn = 0.f;
