@@ -19,6 +19,7 @@ __global__ __launch_bounds__(256) void bn_finalize_k(const float* __restrict__ p
   const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (j >= J) return;
   double s1 = 0.0, s2 = 0.0;
+#pragma unroll 8
   for (long long b = lane; b < nblk; b += 64) {
     s1 += (double)partial[(b * J + j) * 2 + 0];
     s2 += (double)partial[(b * J + j) * 2 + 1];
@@ -87,6 +88,7 @@ __device__ __forceinline__ void bn_bwd_finalize_body(int vb, const float* __rest
   const int j = vb * 4 + (threadIdx.x >> 6);
   if (j >= J) return;
   double s1 = 0.0, s2 = 0.0;
+#pragma unroll 8
   for (long long b = lane; b < nblk; b += 64) {
     s1 += (double)partial[(b * J + j) * 2 + 0];
     s2 += (double)partial[(b * J + j) * 2 + 1];
@@ -261,6 +263,7 @@ __device__ __forceinline__ void reduce_rows_tall_body(long long vb, const float*
   const long long e = vb * 4 + (threadIdx.x >> 6);
   if (e >= len) return;
   double a = 0.0;
+#pragma unroll 8
   for (long long r = lane; r < rows; r += 64) a += (double)src[r * len + e];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
