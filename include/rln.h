@@ -197,6 +197,17 @@ int rln_op_dropout_mask(float* dst, int64_t count, float keep, uint64_t seed, vo
 int rln_preprocess_u8(const uint8_t* frames, int n, int hs, int ws, const uint8_t* labels, int h, int w, int gray,
                       const float* mean3, const float* std3, float* x, int64_t* y, void* stream);
 
+/* rln_augment_u8: the augmenting branch of the same transform (myTransforms.py:8-13): HueSaturationValue ->
+ * RandomSizedCrop resized to h x w -> OneOf(MotionBlur, GaussNoise) -> Normalize -> CHW.  The caller draws the
+ * per-image random parameters and passes them as a DEVICE table params[n][80]:
+ *   0..2 hue/sat/val shift | 3..6 crop y, x, height, width (inside the frame; validated by the caller) |
+ *   7 choice (0 blur, 1 noise) | 8 blur kernel size | 9 noise sigma | 10 noise seed (integer < 2^24) |
+ *   16..64 the 7x7 blur kernel, row-major, centred.
+ * scratch: device [n][h][w][3] bytes.  mean3/std3: HOST pointers.  Parity with albumentations/cv2: unpinned. */
+int rln_augment_u8(const uint8_t* frames, int n, int hs, int ws, const uint8_t* labels, int h, int w,
+                   const float* params, const float* mean3, const float* std3, uint8_t* scratch, float* x, int64_t* y,
+                   void* stream);
+
 /* rln_op_classifier: FCDenseNetClassifier.forward on caller-provided weights (tiramisu.py:120-125):
  * out[n,k,p] = softmax_k((sum_c w[k,c]*feat[n,c,p] + b[k]) / T). */
 int rln_op_classifier(const float* feat, int n, int c, int hw, const float* w, const float* b, int ncls, float T,

@@ -1629,6 +1629,19 @@ int rln_preprocess_u8(const uint8_t* frames, int n, int hs, int ws, const uint8_
   return 0;
 }
 
+int rln_augment_u8(const uint8_t* frames, int n, int hs, int ws, const uint8_t* labels, int h, int w,
+                   const float* params, const float* mean3, const float* std3, uint8_t* scratch, float* x, int64_t* y,
+                   void* stream) {
+  if (!frames || !x || !mean3 || !std3 || !params || !scratch) return fail(RLN_ERR_ARG, "null pointer");
+  if (n < 1 || hs < 2 || ws < 2 || h < 1 || w < 1) return fail(RLN_ERR_ARG, "bad sizes");
+  if ((labels == nullptr) != (y == nullptr)) return fail(RLN_ERR_ARG, "labels and y must be given together");
+  for (int c = 0; c < 3; ++c)
+    if (!(std3[c] > 0.f)) return fail(RLN_ERR_ARG, "std must be positive");
+  RLN_TRY(augment_u8(frames, n, hs, ws, labels, h, w, params, mean3, std3, scratch, x, (long long*)y,
+                     (hipStream_t)stream));
+  return 0;
+}
+
 int rln_op_dropout_mask(float* dst, int64_t count, float keep, uint64_t seed, void* stream) {
   RLN_TRY(dropout_scales(dst, count, keep, (unsigned long long)seed, (hipStream_t)stream));
   return 0;

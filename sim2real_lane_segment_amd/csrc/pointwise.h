@@ -125,6 +125,10 @@ int softmax_channels(const float* x, int N, int C, int HW, float* out, hipStream
 // input transform (myTransforms.py:15-19): uint8 HWC frames -> resized, normalised float CHW (+ nearest-resized labels)
 int preprocess_u8(const unsigned char* frames, int N, int hs, int ws, const unsigned char* labels, int h, int w, int gray,
                   const float* mean3, const float* std3, float* x, long long* y, hipStream_t s);
+// augmenting branch (myTransforms.py:8-13); params: device [N][80] (layout in pointwise.hip), tmp: device [N][h][w][3] bytes
+int augment_u8(const unsigned char* frames, int N, int hs, int ws, const unsigned char* labels, int h, int w,
+               const float* params, const float* mean3, const float* std3, unsigned char* tmp, float* x, long long* y,
+               hipStream_t s);
 
 // ---- misc ----------------------------------------------------------------------------------
 int adamw(float* p, const float* g, float* m, float* v, long long count, float lr, float b1, float b2, float eps,

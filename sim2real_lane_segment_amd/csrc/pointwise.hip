@@ -969,6 +969,163 @@ int preprocess_u8(const unsigned char* frames, int N, int hs, int ws, const unsi
   RLN_LAUNCH_CHECK();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Augmenting branch of the input transform (myTransforms.py:8-13): HueSaturationValue -> RandomSizedCrop (resized
+// to height x width) -> OneOf(MotionBlur, GaussNoise), then Normalize + CHW.  The per-image random parameters are
+// drawn on the host (the reference draws them with Python's `random` per image) and arrive as a table; the
+// per-pixel Gaussian noise is generated here from a counter hash.  Same operations as albumentations 0.5.2 / cv2
+// by their published definitions; parity with those libraries is unpinned (absent here), and a random stream can
+// only match in distribution anyway.
+// params[n][AUG_NP]: 0 hue, 1 sat, 2 val shift | 3 crop_y, 4 crop_x, 5 crop_h, 6 crop_w | 7 choice (0 blur, 1 noise)
+//                    8 ksize | 9 sigma | 10 noise seed | 16.. 7x7 blur kernel (row-major, centred, zeros outside)
+constexpr int AUG_NP = 80;
+
+__device__ __forceinline__ void hsv_shift_u8(int& c0, int& c1, int& c2, float dh, float ds, float dv) {
+#pragma clang fp contract(off)  // plain IEEE multiply/add sequence (checkable against the numpy restatement)
+  // RGB -> HSV (H in [0,180), S, V in [0,255]), LUT shifts as albumentations' uint8 path, HSV -> RGB
+  const int vmax = max(c0, max(c1, c2)), vmin = min(c0, min(c1, c2));
+  const int d = vmax - vmin;
+  float hf = 0.f;
+  if (d != 0) {
+    if (vmax == c0) hf = 30.f * (float)(c1 - c2) / (float)d;
+    else if (vmax == c1) hf = 60.f + 30.f * (float)(c2 - c0) / (float)d;
+    else hf = 120.f + 30.f * (float)(c0 - c1) / (float)d;
+    if (hf < 0.f) hf += 180.f;
+  }
+  int H = (int)rintf(hf);
+  if (H >= 180) H -= 180;
+  const int S = vmax == 0 ? 0 : (int)rintf(255.f * (float)d / (float)vmax);
+  const int V = vmax;
+  float h2 = fmodf((float)H + dh, 180.f);
+  if (h2 < 0.f) h2 += 180.f;
+  const int H2 = (int)h2;                                           // astype(uint8): truncation
+  const int S2 = (int)fminf(fmaxf((float)S + ds, 0.f), 255.f);
+  const int V2 = (int)fminf(fmaxf((float)V + dv, 0.f), 255.f);
+  const float s = (float)S2 * (1.f / 255.f), v = (float)V2 * (1.f / 255.f);
+  const float h6 = (float)H2 * (1.f / 30.f);
+  const int sector = (int)h6;
+  const float f = h6 - (float)sector;
+  const float pp = v * (1.f - s), qq = v * (1.f - s * f), tt = v * (1.f - s * (1.f - f));
+  float r, g, b;
+  switch (sector) {
+    case 0: r = v; g = tt; b = pp; break;
+    case 1: r = qq; g = v; b = pp; break;
+    case 2: r = pp; g = v; b = tt; break;
+    case 3: r = pp; g = qq; b = v; break;
+    case 4: r = tt; g = pp; b = v; break;
+    default: r = v; g = pp; b = qq; break;
+  }
+  c0 = min(max((int)rintf(r * 255.f), 0), 255);
+  c1 = min(max((int)rintf(g * 255.f), 0), 255);
+  c2 = min(max((int)rintf(b * 255.f), 0), 255);
+}
+
+// pass 1: HSV jitter on the four source pixels, crop + bilinear resize (cv2 8-bit fixed point) -> uint8 HWC scratch
+__global__ __launch_bounds__(256) void aug_resize_k(const unsigned char* __restrict__ frames, int hs, int ws,
+                                                    const unsigned char* __restrict__ labels, int h, int w,
+                                                    const float* __restrict__ params, unsigned char* __restrict__ tmp,
+                                                    long long* __restrict__ y) {
+  const int n = blockIdx.y;
+  const int px = blockIdx.x * 256 + threadIdx.x;
+  if (px >= h * w) return;
+  const float* pr = params + (long long)n * AUG_NP;
+  const int cy = (int)pr[3], cx = (int)pr[4], ch = (int)pr[5], cw = (int)pr[6];
+  const int dy = px / w, dx = px - dy * w;
+  int x0, x1, a0, a1, y0, y1, b0, b1;
+  lin_coef(dx, w, cw, &x0, &x1, &a0, &a1);
+  lin_coef(dy, h, ch, &y0, &y1, &b0, &b1);
+  const unsigned char* f = frames + (long long)n * hs * ws * 3;
+  int q[4][3];
+  const int ys[2] = {cy + y0, cy + y1}, xs[2] = {cx + x0, cx + x1};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const unsigned char* s = f + ((long long)ys[k >> 1] * ws + xs[k & 1]) * 3;
+    q[k][0] = s[0];
+    q[k][1] = s[1];
+    q[k][2] = s[2];
+    hsv_shift_u8(q[k][0], q[k][1], q[k][2], pr[0], pr[1], pr[2]);
+  }
+  unsigned char* o = tmp + ((long long)n * h * w + px) * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int r0 = q[0][c] * a0 + q[1][c] * a1, r1 = q[2][c] * a0 + q[3][c] * a1;
+    const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+    o[c] = (unsigned char)min(max(v, 0), 255);
+  }
+  if (labels != nullptr && y != nullptr) {
+    const int sy = min((int)floor((double)dy * ((double)ch / (double)h)), ch - 1);
+    const int sx = min((int)floor((double)dx * ((double)cw / (double)w)), cw - 1);
+    y[(long long)n * h * w + px] = (long long)labels[((long long)n * hs + cy + sy) * ws + cx + sx];
+  }
+}
+
+__device__ __forceinline__ unsigned hash32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+
+// pass 2: MotionBlur (filter2D, BORDER_REFLECT_101) or GaussNoise on the resized image, then Normalize + CHW
+__global__ __launch_bounds__(256) void aug_post_k(const unsigned char* __restrict__ tmp, int h, int w,
+                                                  const float* __restrict__ params, float m0, float m1, float m2,
+                                                  float i0, float i1, float i2, float* __restrict__ x) {
+  const int n = blockIdx.y;
+  const int px = blockIdx.x * 256 + threadIdx.x;
+  if (px >= h * w) return;
+  const float* pr = params + (long long)n * AUG_NP;
+  const int dy = px / w, dx = px - dy * w;
+  const unsigned char* t = tmp + (long long)n * h * w * 3;
+  int v[3];
+  if (pr[7] < 0.5f) {  // motion blur
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int ky = 0; ky < 7; ++ky) {
+      int sy = dy + ky - 3;
+      sy = sy < 0 ? -sy : (sy >= h ? 2 * h - 2 - sy : sy);
+      sy = min(max(sy, 0), h - 1);
+      for (int kx = 0; kx < 7; ++kx) {
+        const float wgt = pr[16 + ky * 7 + kx];
+        if (wgt == 0.f) continue;
+        int sx = dx + kx - 3;
+        sx = sx < 0 ? -sx : (sx >= w ? 2 * w - 2 - sx : sx);
+        sx = min(max(sx, 0), w - 1);
+        const unsigned char* s = t + ((long long)sy * w + sx) * 3;
+        acc[0] = fmaf(wgt, (float)s[0], acc[0]);
+        acc[1] = fmaf(wgt, (float)s[1], acc[1]);
+        acc[2] = fmaf(wgt, (float)s[2], acc[2]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = min(max((int)rintf(acc[c]), 0), 255);
+  } else {  // Gaussian noise, independent per channel: clip(img + N(0, sigma)) -> uint8 (truncation)
+    const float sigma = pr[9];
+    const unsigned seed = (unsigned)pr[10];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const unsigned idx = (unsigned)((n * h * w + px) * 3 + c);
+      const unsigned r1 = hash32(idx * 2u + 1u + seed * 0x9E3779B9u), r2 = hash32(idx * 2u + 2u + seed * 0x85EBCA6Bu);
+      const float u1 = ((float)(r1 >> 8) + 1.f) * (1.f / 16777216.f), u2 = (float)(r2 >> 8) * (1.f / 16777216.f);
+      const float g = sqrtf(-2.f * logf(u1)) * cosf(6.2831853f * u2) * sigma;
+      const float o = (float)t[(long long)px * 3 + c] + g;
+      v[c] = (int)fminf(fmaxf(o, 0.f), 255.f);
+    }
+  }
+  const long long hw = (long long)h * w;
+  float* xo = x + (long long)n * 3 * hw + px;
+  xo[0] = ((float)v[0] - m0) * i0;
+  xo[hw] = ((float)v[1] - m1) * i1;
+  xo[2 * hw] = ((float)v[2] - m2) * i2;
+}
+
+int augment_u8(const unsigned char* frames, int N, int hs, int ws, const unsigned char* labels, int h, int w,
+               const float* params, const float* mean3, const float* std3, unsigned char* tmp, float* x, long long* y,
+               hipStream_t s) {
+  const float m0 = mean3[0] * 255.f, m1 = mean3[1] * 255.f, m2 = mean3[2] * 255.f;
+  const float i0 = 1.f / (std3[0] * 255.f), i1 = 1.f / (std3[1] * 255.f), i2 = 1.f / (std3[2] * 255.f);
+  dim3 grid((unsigned)((h * w + 255) / 256), (unsigned)N);
+  hipLaunchKernelGGL(aug_resize_k, grid, dim3(256), 0, s, frames, hs, ws, labels, h, w, params, tmp, y);
+  hipLaunchKernelGGL(aug_post_k, grid, dim3(256), 0, s, tmp, h, w, params, m0, m1, m2, i0, i1, i2, x);
+  RLN_LAUNCH_CHECK();
+}
+
 // =============================================================================================
 // EncDecNet pieces
 // =============================================================================================

@@ -3,8 +3,10 @@ non-augmenting branch: Resize(height, width) -> [ToGray] -> Normalize() -> ToTen
 (`rln_preprocess_u8`) on uint8 frames that already sit in HBM; no CPU fallback.
 
 Same constructor and call signature as the reference; additionally accepts a whole batch [N, H, W, 3] at once.
-`augment=True` (HueSaturationValue / RandomSizedCrop / MotionBlur / GaussNoise from albumentations) is not built:
-it raises NotImplementedError instead of silently skipping the augmentation."""
+`augment=True` runs the augmenting branch (HueSaturationValue -> RandomSizedCrop -> OneOf(MotionBlur, GaussNoise),
+myTransforms.py:8-13) on device through `rln_augment_u8`: the per-image random parameters are drawn on the host
+(`sample_aug_params`, numpy Generator, `seed=` for reproducibility), the pixels never leave HBM.  The arithmetic
+follows the published definitions of albumentations 0.5.2 / cv2 (absent here): parity unpinned."""
 import ctypes
 
 import numpy as np
@@ -16,15 +18,98 @@ MEAN = (0.485, 0.456, 0.406)
 STD = (0.229, 0.224, 0.225)
 
 
-class MyTransform:
-    def __init__(self, width=160, height=120, gray=False, augment=False, device="cuda"):
-        if augment:
-            raise NotImplementedError("augment=True (albumentations HSV jitter / RandomSizedCrop / blur / noise) is "
-                                      "not available on device yet; use augment=False")
-        self.width, self.height, self.gray = int(width), int(height), bool(gray)
-        self.device = torch.device(device)
+AUG_NP = 80  # floats per image in the parameter table of rln_augment_u8 (layout: include/rln.h)
 
-    def __call__(self, img, label=None):
+
+def _line_kernel(ksize, xs, ys, xe, ye):
+    """cv2.line(kernel, (xs, ys), (xe, ye), 1, thickness=1) on a ksize x ksize grid (Bresenham), normalised."""
+    k = np.zeros((ksize, ksize), np.float32)
+    dx, dy = abs(xe - xs), -abs(ye - ys)
+    sx, sy = (1 if xs < xe else -1), (1 if ys < ye else -1)
+    err, x, y = dx + dy, xs, ys
+    while True:
+        k[y, x] = 1.0
+        if x == xe and y == ye:
+            break
+        e2 = 2 * err
+        if e2 >= dy:
+            err += dy
+            x += sx
+        if e2 <= dx:
+            err += dx
+            y += sy
+    return k / k.sum()
+
+
+def sample_aug_params(n, hs, ws, height, width, rng):
+    """Per-image random parameters of the reference's augmentation pipeline (myTransforms.py:8-13), drawn from the
+    distributions albumentations 0.5.2 documents: HueSaturationValue shifts U(-20,20), U(-30,30), U(-20,20);
+    RandomSizedCrop height randint(height//2, height*4) (clamped to the frame), width = height * w/h, position
+    uniform; OneOf(MotionBlur(3|5|7 line kernel), GaussNoise(var U(10,50))) with equal odds."""
+    out = np.zeros((n, AUG_NP), np.float32)
+    for i in range(n):
+        out[i, 0] = rng.uniform(-20, 20)
+        out[i, 1] = rng.uniform(-30, 30)
+        out[i, 2] = rng.uniform(-20, 20)
+        lo, hi = min(height // 2, hs), min(height * 4, hs)
+        ch = int(rng.integers(lo, hi + 1))
+        cw = min(int(ch * width / height), ws)
+        out[i, 3] = int((hs - ch) * rng.random())
+        out[i, 4] = int((ws - cw) * rng.random())
+        out[i, 5], out[i, 6] = ch, cw
+        if rng.random() < 0.5:
+            ksize = int(rng.choice([3, 5, 7]))
+            xs, xe = int(rng.integers(0, ksize)), int(rng.integers(0, ksize))
+            if xs == xe:
+                ys, ye = (int(v) for v in rng.choice(ksize, 2, replace=False))
+            else:
+                ys, ye = int(rng.integers(0, ksize)), int(rng.integers(0, ksize))
+            k = _line_kernel(ksize, xs, ys, xe, ye)
+            off = (7 - ksize) // 2
+            full = np.zeros((7, 7), np.float32)
+            full[off:off + ksize, off:off + ksize] = k
+            out[i, 7], out[i, 8] = 0, ksize
+            out[i, 16:16 + 49] = full.reshape(-1)
+        else:
+            out[i, 7] = 1
+            out[i, 9] = np.sqrt(rng.uniform(10, 50))
+            out[i, 10] = int(rng.integers(0, 1 << 24))
+    return out
+
+
+class MyTransform:
+    def __init__(self, width=160, height=120, gray=False, augment=False, device="cuda", seed=None):
+        if augment and gray:
+            raise NotImplementedError("augment=True with gray=True is not built (no reference script uses it)")
+        self.width, self.height, self.gray, self.augment = int(width), int(height), bool(gray), bool(augment)
+        self.device = torch.device(device)
+        self.rng = np.random.default_rng(seed)
+
+    def _augment(self, x, y_in, n, hs, ws, have_label, params=None):
+        if params is None:
+            params = sample_aug_params(n, hs, ws, self.height, self.width, self.rng)
+        params = np.ascontiguousarray(params, np.float32)
+        if params.shape != (n, AUG_NP):
+            raise ValueError("params must be [N, 80]")
+        if (params[:, 3] < 0).any() or (params[:, 4] < 0).any() or (params[:, 5] < 1).any() or (params[:, 6] < 1).any() \
+                or (params[:, 3] + params[:, 5] > hs).any() or (params[:, 4] + params[:, 6] > ws).any():
+            raise ValueError("crop box outside the frame")
+        self.last_params = params
+        pd = torch.from_numpy(params).to(self.device)
+        out = torch.empty((n, 3, self.height, self.width), dtype=torch.float32, device=self.device)
+        tmp = torch.empty((n, self.height, self.width, 3), dtype=torch.uint8, device=self.device)
+        y_out = torch.empty((n, self.height, self.width), dtype=torch.int64, device=self.device) if have_label else None
+        mean = (ctypes.c_float * 3)(*MEAN)
+        std = (ctypes.c_float * 3)(*STD)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(_lib.lib().rln_augment_u8(x.data_ptr(), n, hs, ws, y_in.data_ptr() if have_label else None,
+                                             self.height, self.width, pd.data_ptr(), mean, std, tmp.data_ptr(),
+                                             out.data_ptr(), y_out.data_ptr() if have_label else None, stream),
+                   "rln_augment_u8")
+        self._keep = (x, y_in, pd, tmp)
+        return out, y_out
+
+    def __call__(self, img, label=None, params=None):
         single = (img.ndim == 3)
         x = torch.as_tensor(np.ascontiguousarray(img) if isinstance(img, np.ndarray) else img)
         if x.dtype != torch.uint8 or x.shape[-1] != 3:
@@ -40,6 +125,11 @@ class MyTransform:
             if y_in.dtype != torch.uint8:
                 raise ValueError("expected a uint8 label mask")
             y_in = y_in.to(self.device).contiguous().reshape(n, hs, ws)
+        if self.augment:
+            out, y_out = self._augment(x, y_in, n, hs, ws, have_label, params)
+            if single:
+                return out[0], (y_out[0] if have_label else label)
+            return out, (y_out if have_label else label)
         out = torch.empty((n, 3, self.height, self.width), dtype=torch.float32, device=self.device)
         y_out = torch.empty((n, self.height, self.width), dtype=torch.int64, device=self.device) if have_label else None
         mean = (ctypes.c_float * 3)(*MEAN)
