@@ -155,6 +155,7 @@ struct rln_ctx {
   const float* last_x = nullptr;
   const int64_t* last_y = nullptr;
   int have_train_fwd = 0, have_loss = 0;
+  long long prep_done = -1;  // op whose bn_prep already ran with the previous op's bn_finalize
   int loss_mode = 0;      // 0: weighted CE (rln_loss), 1: entropy with gradient reversal (rln_entropy_loss)
   float loss_lamda = 0.f;
   const float* last_scales = nullptr;
@@ -603,17 +604,37 @@ struct ProfScope {
 // forward ops
 // ---------------------------------------------------------------------------------------------
 
-int finalize_stats(rln_ctx* c, int level, int ch_off, int J, long long nblk, hipStream_t s) {
+// k: index of the op that produced the channels; when the next op normalises a range of the same level that
+// contains them, its bn_prep rides in the same launch (c->prep_done = index of that op).
+int finalize_stats(rln_ctx* c, int level, int ch_off, int J, long long nblk, hipStream_t s, long long k = -1) {
   const Level& lv = c->levels[level];
   const double count = (double)c->N * lv.H * lv.W;
   const int64_t so = lv.stat_off + ch_off;
   ProfScope ps(c, PC_BN, 0, 0, s);
+  static const bool nofuse = getenv("RLN_NO_BNFUSE") != nullptr;
+  if (!nofuse && k >= 0 && (size_t)(k + 1) < c->ops.size()) {
+    const Op& nx = c->ops[(size_t)k + 1];
+    if ((nx.type == OP_DENSE || nx.type == OP_TD) && nx.src_level == level && nx.in_off <= ch_off &&
+        ch_off + J <= nx.in_off + nx.bn.C) {
+      const int64_t son = lv.stat_off + nx.in_off;
+      RLN_TRY(bn_finalize_prep(c->stat_partial, nblk, J, ch_off - nx.in_off, count, c->cfg.bn_eps, c->mean + son,
+                               c->var + son, c->invstd + son, c->stdv + son, nx.bn.C, c->params + nx.bn.gamma,
+                               c->params + nx.bn.beta, c->bnrun + nx.bn.rmean, c->bnrun + nx.bn.rvar,
+                               c->cfg.bn_momentum, c->ab + nx.bn.ab, c->ab + c->n_ab + nx.bn.ab, s));
+      c->prep_done = k + 1;
+      return 0;
+    }
+  }
   RLN_TRY(bn_finalize(c->stat_partial, nblk, J, count, c->cfg.bn_eps, c->mean + so, c->var + so, c->invstd + so,
                       c->stdv + so, s));
   return 0;
 }
 
-int prep_bn(rln_ctx* c, const Op& o, int training, hipStream_t s) {
+int prep_bn(rln_ctx* c, const Op& o, int training, hipStream_t s, long long k = -1) {
+  if (training && k >= 0 && c->prep_done == k) {  // done together with the previous op's statistics
+    c->prep_done = -1;
+    return 0;
+  }
   const Level& lv = c->levels[o.src_level];
   const int64_t so = lv.stat_off + o.in_off;
   const double count = (double)c->N * lv.H * lv.W;
@@ -663,7 +684,7 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
     p.GW = dl.W;
   } else if (o.type == OP_DENSE) {
     kind = IG_CONV3_BN;
-    RLN_TRY(prep_bn(c, o, training, s));
+    RLN_TRY(prep_bn(c, o, training, s, (long long)k));
     p.in = dl.S + (size_t)o.in_off * dl.H * dl.W;
     p.in_ns = p.out_ns;
     p.in_cs = p.out_cs;
@@ -677,7 +698,7 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
     p.GW = dl.W;
   } else if (o.type == OP_TD) {
     kind = IG_CONV1_POOL;
-    RLN_TRY(prep_bn(c, o, training, s));
+    RLN_TRY(prep_bn(c, o, training, s, (long long)k));
     const Level& sl = c->levels[o.src_level];
     p.in = sl.S + (size_t)o.in_off * sl.H * sl.W;
     p.in_ns = (long long)sl.C * sl.H * sl.W;
@@ -744,12 +765,12 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
       long long nblk = 0;
       RLN_TRY(splitk_finish(c->fsplit, sp, q.split_stride, N, o.cout, HW, p.bias, p.nscale, p.out, p.out_ns,
                             p.stat_partial, &nblk, s));
-      if (training) RLN_TRY(finalize_stats(c, o.dst_level, o.out_off, o.cout, nblk, s));
+      if (training) RLN_TRY(finalize_stats(c, o.dst_level, o.out_off, o.cout, nblk, s, (long long)k));
       return 0;
     }
     RLN_TRY(igemm_launch(kind, tile, p, N, s));
   }
-  if (training) RLN_TRY(finalize_stats(c, o.dst_level, o.out_off, o.cout, igemm_stat_blocks(p, N), s));
+  if (training) RLN_TRY(finalize_stats(c, o.dst_level, o.out_off, o.cout, igemm_stat_blocks(p, N), s, (long long)k));
   return 0;
 }
 
@@ -1272,6 +1293,7 @@ int rln_forward(rln_ctx* c, const float* x, int n, int h, int w, int training, c
     }
     if (c->nbt) RLN_TRY(add_one_i64((long long*)c->nbt, c->n_nbt, s));
   }
+  c->prep_done = -1;
   for (size_t k = 0; k < c->ops.size(); ++k) RLN_TRY(fwd_op(c, k, x, training, s));
   if (probs_out || feat_out) {
     HeadParams hp = head_params(c);

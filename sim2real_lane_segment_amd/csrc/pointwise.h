@@ -12,6 +12,10 @@ int bn_finalize(const float* partial, long long nblk, int J, double count, float
                 float* invstd, float* stdv, hipStream_t s);
 // folds a BatchNorm2d into per-channel (a, b): train -> batch stats (+ running-stat update, momentum,
 // unbiased var); eval -> running stats.
+// bn_finalize of the new channels + bn_prep (training form) of the next BatchNorm over [0, C) (new at [new_lo, new_lo+Jnew))
+int bn_finalize_prep(const float* partial, long long nblk, int Jnew, int new_lo, double count, float eps, float* mean,
+                     float* var, float* invstd, float* stdv, int C, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float momentum, float* a, float* b, hipStream_t s);
 int bn_prep(int training, int C, const float* gamma, const float* beta, const float* mean, const float* var,
             const float* invstd, float* running_mean, float* running_var, float momentum, double count, float eps,
             float* a, float* b, hipStream_t s);

@@ -41,6 +41,71 @@ __global__ __launch_bounds__(256) void bn_finalize_k(const float* __restrict__ p
   }
 }
 
+// bn_finalize of the channels a layer has just written + bn_prep of the NEXT layer's BatchNorm over its whole input
+// range, in one launch (they are adjacent in the stream and each costs a dependent-dispatch gap).  One wave per
+// channel c of the next BatchNorm; channels [new_lo, new_lo + Jnew) are the new ones.  Same arithmetic and
+// summation order as the two stand-alone kernels.
+__global__ __launch_bounds__(256) void bn_finalize_prep_k(const float* __restrict__ partial, long long nblk, int Jnew,
+                                                          int new_lo, double count, float eps, float* mean, float* var,
+                                                          float* invstd, float* stdv, int C,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* running_mean, float* running_var, float momentum,
+                                                          float unbias, float* a, float* b) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= C) return;
+  float m, vr, is;
+  const int j = c - new_lo;
+  if (j >= 0 && j < Jnew) {
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll 8
+    for (long long bb = lane; bb < nblk; bb += 64) {
+      s1 += (double)partial[(bb * Jnew + j) * 2 + 0];
+      s2 += (double)partial[(bb * Jnew + j) * 2 + 1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s1 += __shfl_xor(s1, o, 64);
+      s2 += __shfl_xor(s2, o, 64);
+    }
+    const double md = s1 / count;
+    double v = s2 / count - md * md;
+    if (v < 0.0) v = 0.0;
+    m = (float)md;
+    vr = (float)v;
+    const float sd = sqrtf(vr + eps);
+    is = 1.0f / sd;
+    if (lane == 0) {
+      mean[c] = m;
+      var[c] = vr;
+      invstd[c] = is;
+      stdv[c] = sd;
+    }
+  } else {
+    m = mean[c];
+    vr = var[c];
+    is = invstd[c];
+  }
+  if (lane == 0) {
+    const float av = gamma[c] * is;
+    a[c] = av;
+    b[c] = beta[c] - m * av;
+    if (running_mean != nullptr) {
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (vr * unbias);
+    }
+  }
+}
+
+int bn_finalize_prep(const float* partial, long long nblk, int Jnew, int new_lo, double count, float eps, float* mean,
+                     float* var, float* invstd, float* stdv, int C, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float momentum, float* a, float* b, hipStream_t s) {
+  const float unbias = count > 1.0 ? (float)(count / (count - 1.0)) : 1.0f;
+  hipLaunchKernelGGL(bn_finalize_prep_k, dim3((C + 3) / 4), dim3(256), 0, s, partial, nblk, Jnew, new_lo, count, eps,
+                     mean, var, invstd, stdv, C, gamma, beta, running_mean, running_var, momentum, unbias, a, b);
+  RLN_LAUNCH_CHECK();
+}
+
 int bn_finalize(const float* partial, long long nblk, int J, double count, float eps, float* mean, float* var,
                 float* invstd, float* stdv, hipStream_t s) {
   hipLaunchKernelGGL(bn_finalize_k, dim3((J + 3) / 4), dim3(256), 0, s, partial, nblk, J, count, eps, mean, var,
