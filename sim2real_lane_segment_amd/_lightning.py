@@ -54,12 +54,23 @@ except Exception:  # ModuleNotFoundError here and on the GPU box
 
         @classmethod
         def load_from_checkpoint(cls, checkpoint_path, map_location=None, strict=True, **kwargs):
-            """Reads a Lightning-style checkpoint ({'state_dict', 'hyper_parameters'}) or a bare state_dict."""
+            """Reads a Lightning-style checkpoint ({'state_dict', 'hyper_parameters'}) or a bare state_dict.
+
+            Weights-only: the file is parsed by ``torch.load(..., weights_only=True)`` and nothing else, so a checkpoint
+            can never execute code.  ``hyper_parameters`` saved as an ``argparse.Namespace`` (Lightning does that for
+            argparse-driven scripts) are admitted through ``torch.serialization.safe_globals``; any other pickled
+            object makes the load fail with an error naming the file."""
+            import argparse
             try:
-                ckpt = torch.load(checkpoint_path, map_location=map_location or "cpu", weights_only=True)
-            except Exception:
-                ckpt = torch.load(checkpoint_path, map_location=map_location or "cpu", weights_only=False)
-            hp = dict(ckpt.get("hyper_parameters", {})) if isinstance(ckpt, dict) else {}
+                with torch.serialization.safe_globals([argparse.Namespace]):
+                    ckpt = torch.load(checkpoint_path, map_location=map_location or "cpu", weights_only=True)
+            except Exception as exc:
+                raise RuntimeError(
+                    f"checkpoint {checkpoint_path!r} could not be read by the weights-only loader ({exc}); "
+                    f"refusing to unpickle arbitrary objects. Re-save it as a plain state_dict / "
+                    f"{{'state_dict', 'hyper_parameters'}} of tensors and numbers.") from exc
+            hp = ckpt.get("hyper_parameters", {}) if isinstance(ckpt, dict) else {}
+            hp = dict(vars(hp)) if isinstance(hp, argparse.Namespace) else dict(hp)
             hp.update(kwargs)
             sig = inspect.signature(cls.__init__).parameters
             model = cls(**{k: v for k, v in hp.items() if k in sig})

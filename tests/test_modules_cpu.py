@@ -55,6 +55,35 @@ def test_checkpoint_loading_like_test_py(tmp_path):
     assert torch.equal(m2.featureExtractor.firstconv.weight, m.featureExtractor.firstconv.weight)
 
 
+def test_checkpoint_with_namespace_hparams_and_hostile_pickle(tmp_path):
+    """weights-only loader: an argparse.Namespace of numbers is admitted, a pickled callable is rejected loudly."""
+    import pickle
+    m = SimpleTrainModule(num_cls=4)
+    ok = tmp_path / "ns.ckpt"
+    torch.save({"state_dict": m.state_dict(), "hyper_parameters": argparse.Namespace(lr=2e-3, decay=1e-4, lrRatio=5.0)},
+               ok)
+    m2 = SimpleTrainModule.load_from_checkpoint(checkpoint_path=str(ok), num_cls=4)
+    assert m2.lr == 2e-3 and m2.lrRatio == 5.0
+
+    marker = tmp_path / "executed"
+
+    class Hostile:
+        def __reduce__(self):
+            import os
+            return (os.system, (f"touch {marker}",))
+
+    bad = tmp_path / "bad.ckpt"
+    torch.save({"state_dict": m.state_dict(), "hyper_parameters": {"lr": Hostile()}}, bad)
+    with pytest.raises(RuntimeError, match="weights-only"):
+        SimpleTrainModule.load_from_checkpoint(checkpoint_path=str(bad), num_cls=4)
+    assert not marker.exists()
+    raw = tmp_path / "raw.ckpt"
+    raw.write_bytes(pickle.dumps({"state_dict": {}, "hyper_parameters": Hostile()}))
+    with pytest.raises(RuntimeError, match="weights-only"):
+        SimpleTrainModule.load_from_checkpoint(checkpoint_path=str(raw), num_cls=4)
+    assert not marker.exists()
+
+
 def test_cli_flags_and_optimizers():
     parser = TrainingBase.add_model_specific_args(argparse.ArgumentParser())
     a = parser.parse_args(["-lr", "0.01", "--decay", "0.001", "--lrRatio", "50"])
