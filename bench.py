@@ -101,10 +101,10 @@ def host_cores():
     return max(1, n)
 
 
-def cpu_baseline(batch=8, budget_s=25.0):
+def cpu_baseline(batch=8, timed=5, budget_s=60.0):
     """The CPU oracle (a port of the reference step onto stock PyTorch CPU operators) on the host cores.
-    Bounded sample: one warm-up step at batch 2, then batch-`batch` training steps until two are timed or the
-    budget is spent (at least one)."""
+    Bounded sample: one warm-up step, then `timed` training steps at batch 8 -> median; one more step
+    at batch 64 (the metric's batch) when what is left of the budget allows it."""
     from oracle import fcdensenet_oracle as O
     from sim2real_lane_segment_amd.synthetic import make_batch
     cores = host_cores()
@@ -112,20 +112,57 @@ def cpu_baseline(batch=8, budget_s=25.0):
     print(f"[bench] cpu_baseline on {cores} threads ...", file=sys.stderr, flush=True)
     cfg = O.fcdensenet67_config(4)
     ts = O.TrainState(O.init_state(cfg, 0))
-    xw, yw = make_batch(2, seed=7)
-    O.train_step(ts, xw, yw, cfg, O.make_drop_scales(cfg, 2, 99))
     x, y = make_batch(batch, seed=42)
-    times = []
     t_start = time.perf_counter()
-    while len(times) < 2 and (not times or time.perf_counter() - t_start + times[-1] < budget_s):
+    O.train_step(ts, x, y, cfg, O.make_drop_scales(cfg, batch, 99))  # warm-up (allocator, thread pool)
+    times = []
+    while len(times) < timed and (len(times) < 1 or time.perf_counter() - t_start + times[-1] < budget_s):
         scales = O.make_drop_scales(cfg, batch, 100 + len(times))
         t0 = time.perf_counter()
         O.train_step(ts, x, y, cfg, scales)
         times.append(time.perf_counter() - t0)
-    t = min(times)
-    return {"value": round(batch / t, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{len(times)} timed training step(s) (fwd+weighted CE+bwd+AdamW) at batch {batch} after one "
-                      f"batch-2 warm-up step, 120x160, fp32, best of the timed steps"}
+    med = sorted(times)[len(times) // 2]
+    out = {"value": round(batch / med, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"median of {len(times)} timed training steps (fwd+weighted CE+bwd+AdamW) at batch {batch} after "
+                     f"one warm-up step, 120x160, fp32, oracle/fcdensenet_oracle.py on stock PyTorch CPU operators"}
+    if time.perf_counter() - t_start + 8.5 * med < budget_s:  # a batch-64 step costs ~8x a batch-8 step
+        x64, y64 = make_batch(64, seed=43)
+        scales = O.make_drop_scales(cfg, 64, 7)
+        t0 = time.perf_counter()
+        O.train_step(ts, x64, y64, cfg, scales)
+        out["batch64_value"] = round(64 / (time.perf_counter() - t0), 4)
+        out["sample"] += "; batch64_value = one timed step at batch 64"
+    return out
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: starts N fresh worker processes (one per device, RCCL
+    rendezvous on 127.0.0.1) BEFORE this process touches the GPU, relays rank 0's JSON line and fails loudly if
+    the box has fewer than N devices or any rank fails."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()  # counting devices does not initialise the GPU
+    if have < n:
+        print(f"[bench] --gpus {n} requested but only {have} device(s) are visible", file=sys.stderr)
+        return 3
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    codes = [p.wait() for p in procs]
+    if any(codes):
+        print(f"[bench] rank exit codes {codes}", file=sys.stderr)
+        return 4
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return 0
 
 
 def main():
@@ -141,7 +178,18 @@ def main():
     ap.add_argument("--buckets", type=int, default=4)
     ap.add_argument("--force-dist", action="store_true",
                     help="single-GPU plumbing check: 1-rank RCCL process group + the bucketed all-reduce path")
+    ap.add_argument("--api", choices=("engine", "module"), default="engine",
+                    help="engine: TrainStepper (direct C-ABI calls, overlapped all-reduce); module: the reference-shaped "
+                         "path training_step -> loss.backward() -> optimizer.step() (what Lightning drives)")
+    ap.add_argument("--no-module-api", action="store_true", help="skip the secondary module-API timing")
     args = ap.parse_args()
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    if env_world is not None and int(env_world) != args.gpus and not args.force_dist:
+        print(f"[bench] --gpus {args.gpus} contradicts WORLD_SIZE={env_world}", file=sys.stderr)
+        sys.exit(2)
 
     # Libraries (RCCL prints a banner at communicator creation) must not pollute stdout: the contract is ONE JSON
     # line there.  Everything until the final print goes to stderr at the file-descriptor level.
@@ -173,6 +221,31 @@ def main():
     eng = model._rln_sync()
     stepper = TrainStepper(eng, lr=1e-3, weight_decay=1e-4, n_buckets=args.buckets, force_collectives=args.force_dist)
     stepper.broadcast_parameters()
+    if dist.is_initialized() and dist.get_world_size() != world:
+        print(f"[bench] RCCL world size {dist.get_world_size()} != WORLD_SIZE {world}", file=sys.stderr)
+        sys.exit(5)
+
+    class ModuleStepper:
+        """The reference-shaped path: what Lightning runs per batch (SimpleTrain.py:11-30)."""
+
+        def __init__(self, module):
+            self.module = module
+            (self.opt,), _ = module.configure_optimizers()
+
+        def step(self, x, y):
+            self.opt.zero_grad(set_to_none=True)
+            loss = self.module.training_step((x, y), 0)
+            loss.backward()
+            if world > 1:  # un-overlapped mean over ranks of the flat gradient the backward handed to autograd
+                flat = self.opt.param_groups[0]["params"][0].grad._base
+                dist.all_reduce(flat)
+                flat.mul_(1.0 / world)
+            self.opt.step()
+            return loss.detach().reshape(1)
+
+    engine_stepper = stepper
+    if args.api == "module":
+        stepper = ModuleStepper(model)
 
     B = args.batch
     pool = [make_batch(B, args.height, args.width, seed=42, first_index=(rank * 4 + i) * B, device=dev)
@@ -205,6 +278,20 @@ def main():
     # the per-class kernel durations they measure are the quantity the roofline needs. ----
     prof = None
     instrumented_ms = None
+    module_api = None
+    if args.api == "engine" and world == 1 and not args.no_module_api:
+        ms = ModuleStepper(model)
+        for i in range(2):
+            ms.step(*pool[i % len(pool)])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            ms.step(*pool[i % len(pool)])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        module_api = {"value": round(B * args.steps / dt, 2), "unit": "images/sec",
+                      "ms_per_step": round(1000.0 * dt / args.steps, 3),
+                      "path": "SimpleTrainModule.training_step -> loss.backward() -> FusedAdamW.step()"}
     if not args.no_profile:
         _lib.check(_lib.lib().rln_profile_enable(eng.ctx, 1))
         torch.cuda.synchronize()
@@ -235,8 +322,11 @@ def main():
             "config": {"workload": f"FCDenseNet67 num_cls=4 SimpleTrainModule training step (fwd+weighted CE+bwd+AdamW), "
                                    f"per-GPU batch {B}, 3x{args.height}x{args.width} synthetic Duckietown frames, "
                                    f"random-init weights, Dropout2d+BatchNorm in train mode",
-                       "global_batch": world * B, "parallelism": f"dp{world}", "final_loss": round(loss, 5)},
+                       "global_batch": world * B, "parallelism": f"dp{world}", "final_loss": round(loss, 5),
+                       "api": args.api},
         }
+        if module_api is not None:
+            result["module_api"] = module_api
         if prof is not None:
             timed = [p for p in prof if p["launches"] > 0]
             total_ms = sum(p["ms"] for p in timed)

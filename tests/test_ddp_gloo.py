@@ -10,7 +10,8 @@ import torch.multiprocessing as mp
 
 from oracle import fcdensenet_oracle as O
 from sim2real_lane_segment_amd.engine import Engine, NetSpec
-from sim2real_lane_segment_amd.trainer import BucketedGradReducer, plan_buckets
+from sim2real_lane_segment_amd import _lib
+from sim2real_lane_segment_amd.trainer import BucketedGradReducer, TrainStepper, plan_buckets
 
 
 def _free_port():
@@ -63,3 +64,87 @@ def test_two_rank_bucketed_allreduce(tmp_path):
     for r in range(2):
         res = torch.load(os.path.join(str(tmp_path), f"r{r}.pt"), weights_only=False)
         assert res["ok"], f"rank {r} saw wrong reduced gradients"
+
+
+# ---- TrainStepper itself on two gloo ranks -----------------------------------------------------------------
+# The HIP kernels need a GPU; everything else of the DDP step does not.  A recorded-gradient engine replays, segment
+# by segment and in the engine's REAL segment plan, the gradient arena the CPU oracle computed for this rank's batch
+# (different batches per rank), and applies the oracle's AdamW to the flat arena.  Checked: (i) the reduced arena is
+# the mean of the two single-rank arenas, (ii) parameters stay bit-identical across ranks, (iii) they equal AdamW
+# applied to the mean gradient.
+class _RecordedEngine:
+    def __init__(self, real, recorded):
+        self.seg_ranges, self.n_seg, self.n_param = real.seg_ranges, real.n_seg, real.n_param
+        self.params = real.params.clone()
+        self.bnrun = real.bnrun.clone()
+        self.grads = torch.zeros(real.n_param)
+        self.recorded = recorded
+        self.order = []
+
+    def forward(self, x, training, with_backward, drop_scales=None, seed=None):
+        return torch.zeros(1), None
+
+    def loss(self, probs, y, weighted):
+        return torch.zeros(7), None, None
+
+    def backward(self, loss_scale, sb, se):
+        for s in range(sb, se):
+            b, e = self.seg_ranges[s]
+            self.grads[b:e] = self.recorded[b:e] * loss_scale
+            self.order.append(s)
+
+    def adamw_step(self, m, v, step, lr, betas, eps, wd, grad_scale=1.0):
+        O.adamw_step(self.params, self.grads * grad_scale, m, v, step, lr, betas[0], betas[1], eps, wd)
+
+
+def _oracle_grad_arena(eng, seed):
+    cfg = O.fcdensenet67_config(4)
+    st = O.init_state(cfg, 0)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(2, 3, 32, 32, generator=g)
+    y = torch.randint(0, 4, (2, 32, 32), generator=g)
+    _, _, gd, _ = O.train_step(O.TrainState(st), x, y, cfg, O.make_drop_scales(cfg, 2, seed), apply_update=False)
+    flat = torch.zeros(eng.n_param)
+    for m in eng.metas:
+        if m.kind == _lib.T_PARAM:
+            flat[m.offset:m.offset + m.numel] = gd[m.name].reshape(-1)
+    return flat
+
+
+def _stepper_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    real = Engine(NetSpec(n_classes=4), device="cpu")
+    real.load_state(O.init_state(O.fcdensenet67_config(4), 0))
+    rec = _oracle_grad_arena(real, 100 + rank)
+    eng = _RecordedEngine(real, rec)
+    if rank == 1:
+        eng.params.add_(1.0)  # broadcast_parameters must overwrite this with rank 0's values
+    stepper = TrainStepper(eng, lr=1e-3, weight_decay=1e-4, n_buckets=4)
+    stepper.broadcast_parameters()
+    assert stepper.world == world and len(stepper.reducer.buckets) >= 2
+    stepper.step(None, None)
+    torch.save({"params": eng.params, "reduced": eng.grads.clone(), "own": rec, "order": eng.order},
+               os.path.join(out_dir, f"s{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_train_stepper_real_segments(tmp_path):
+    port = _free_port()
+    mp.spawn(_stepper_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), f"s{k}.pt"), weights_only=True) for k in range(2)]
+    mean = (r[0]["own"] + r[1]["own"]) / 2
+    assert r[0]["own"].abs().max() > 0 and not torch.equal(r[0]["own"], r[1]["own"])
+    for k in range(2):
+        assert torch.allclose(r[k]["reduced"] / 2, mean, rtol=1e-6, atol=1e-12)   # (i) sum over ranks, mean by 1/world
+        assert r[k]["order"] == list(range(len(r[k]["order"])))
+    assert torch.equal(r[0]["params"], r[1]["params"])                                # (ii)
+    eng = Engine(NetSpec(n_classes=4), device="cpu")
+    eng.load_state(O.init_state(O.fcdensenet67_config(4), 0))
+    p = eng.params.clone()
+    O.adamw_step(p, (r[0]["own"] + r[1]["own"]) * 0.5, torch.zeros_like(p), torch.zeros_like(p), 1, 1e-3,
+                 weight_decay=1e-4)
+    assert torch.allclose(r[0]["params"], p, rtol=0, atol=2e-7)                       # (iii)
