@@ -208,6 +208,16 @@ int rln_augment_u8(const uint8_t* frames, int n, int hs, int ws, const uint8_t* 
                    const float* params, const float* mean3, const float* std3, uint8_t* scratch, float* x, int64_t* y,
                    void* stream);
 
+/* rln_overlay_u8: the per-frame tail of makeDemoVideo.py:36-46 on device.  pred = argmax over classes of probs
+ * [n][ncls][h][w] (first maximum wins, torch.max(out, 1)); out [n][h][w][3] uint8 = the frame resized to (h, w) with
+ * cv2's 8-bit INTER_LINEAR arithmetic (the script's `cv2.resize(frame, framesize, cv2.INTER_LANCZOS4)` passes the flag
+ * in the dst position, so the default interpolation applies), with out[pred == k] = colors_host[k] for every class k
+ * whose bit is set in paint_mask (the script paints 1 -> (0,255,0), 2 -> (255,0,0), 3 -> (0,0,255), BGR).
+ * colors_host: HOST pointer to ncls*3 bytes; pred_out: optional [n][h][w] uint8 class map (pred.byte()).
+ * Resize parity with cv2 is unpinned (cv2 absent); argmax and painting are exact. */
+int rln_overlay_u8(const uint8_t* frames, int n, int hs, int ws, const float* probs, int ncls, int h, int w,
+                   const uint8_t* colors_host, unsigned paint_mask, uint8_t* out, uint8_t* pred_out, void* stream);
+
 /* rln_op_classifier: FCDenseNetClassifier.forward on caller-provided weights (tiramisu.py:120-125):
  * out[n,k,p] = softmax_k((sum_c w[k,c]*feat[n,c,p] + b[k]) / T). */
 int rln_op_classifier(const float* feat, int n, int c, int hw, const float* w, const float* b, int ncls, float T,

@@ -161,3 +161,15 @@ def augment(img, label, params, n_index, width=160, height=120):
     x = (v.astype(f32) - mean) * inv
     y = None if label is None else resize_nearest(label[cy:cy + ch, cx:cx + cw], height, width).astype(np.int64)
     return np.ascontiguousarray(x.transpose(2, 0, 1)), y
+
+
+def overlay(frame, probs, colors=((0, 0, 0), (0, 255, 0), (255, 0, 0), (0, 0, 255)), paint=(1, 2, 3)):
+    """makeDemoVideo.py:36-46 for one frame: pred = argmax (first maximum), frame_out = cv2.resize(frame, (w, h))
+    [default INTER_LINEAR: the script's third positional argument is `dst`], frame_out[pred == k] = colors[k].
+    frame uint8 [hs, ws, 3], probs float32 [K, h, w] -> (uint8 [h, w, 3], uint8 [h, w])."""
+    k, h, w = probs.shape
+    pred = np.argmax(probs, axis=0).astype(np.uint8)
+    out = resize_linear_u8(frame, h, w).copy()
+    for c in paint:
+        out[pred == c] = np.array(colors[c], np.uint8)
+    return out, pred

@@ -81,6 +81,8 @@ _PROTOS = {
                                   POINTER(c_float), c_void_p, c_void_p, c_void_p]),
     "rln_augment_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, POINTER(c_float),
                                POINTER(c_float), c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rln_overlay_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, ctypes.c_uint,
+                               c_void_p, c_void_p, c_void_p]),
     "rln_op_classifier": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_int,
                                   c_void_p]),
 }

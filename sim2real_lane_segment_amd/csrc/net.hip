@@ -1664,6 +1664,15 @@ int rln_augment_u8(const uint8_t* frames, int n, int hs, int ws, const uint8_t* 
   return 0;
 }
 
+int rln_overlay_u8(const uint8_t* frames, int n, int hs, int ws, const float* probs, int ncls, int h, int w,
+                   const uint8_t* colors_host, unsigned paint_mask, uint8_t* out, uint8_t* pred_out, void* stream) {
+  if (!frames || !probs || !colors_host || !out) return fail(RLN_ERR_ARG, "null pointer");
+  if (n < 1 || hs < 1 || ws < 1 || h < 1 || w < 1 || ncls < 1 || ncls > 16) return fail(RLN_ERR_ARG, "bad sizes");
+  RLN_TRY(overlay_u8(frames, n, hs, ws, probs, ncls, h, w, colors_host, paint_mask, out, pred_out,
+                     (hipStream_t)stream));
+  return 0;
+}
+
 int rln_op_dropout_mask(float* dst, int64_t count, float keep, uint64_t seed, void* stream) {
   RLN_TRY(dropout_scales(dst, count, keep, (unsigned long long)seed, (hipStream_t)stream));
   return 0;

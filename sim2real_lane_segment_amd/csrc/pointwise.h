@@ -134,6 +134,11 @@ int augment_u8(const unsigned char* frames, int N, int hs, int ws, const unsigne
                const float* params, const float* mean3, const float* std3, unsigned char* tmp, float* x, long long* y,
                hipStream_t s);
 
+// demo overlay (makeDemoVideo.py:36-46): argmax + bilinear-resized frame + class colours, uint8 HWC out
+int overlay_u8(const unsigned char* frames, int N, int hs, int ws, const float* probs, int ncls, int h, int w,
+               const unsigned char* colors_host, unsigned paint_mask, unsigned char* out, unsigned char* pred_out,
+               hipStream_t s);
+
 // ---- misc ----------------------------------------------------------------------------------
 int adamw(float* p, const float* g, float* m, float* v, long long count, float lr, float b1, float b2, float eps,
           float wd, int step, float grad_scale, hipStream_t s);

@@ -3,6 +3,8 @@
 // partials + fixed-order second stage instead of float atomics (bitwise reproducible results).
 #include "pointwise.h"
 
+#include <cstring>
+
 namespace rln {
 
 #define RLN_LAUNCH_CHECK() return (int)hipGetLastError()
@@ -1031,6 +1033,68 @@ int preprocess_u8(const unsigned char* frames, int N, int hs, int ws, const unsi
   dim3 grid((unsigned)((h * w + 255) / 256), (unsigned)N);
   hipLaunchKernelGGL(preprocess_u8_k, grid, dim3(256), 0, s, frames, hs, ws, labels, h, w, gray, m0, m1, m2, i0, i1, i2,
                      x, y);
+  RLN_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Demo overlay (makeDemoVideo.py:36-46): pred = argmax_k probs (first maximum wins, torch.max(out, 1)), frame_out =
+// cv2.resize(frame, (w, h)) [the script passes INTER_LANCZOS4 in the `dst` position, so the interpolation is the
+// default INTER_LINEAR: the same 8-bit fixed-point resize as above], then frame_out[pred == k] = colour[k] for the
+// classes the script paints.  One pass: uint8 HWC frame + probabilities in, uint8 HWC frame out.
+struct OverlayColors {
+  unsigned char bgr[16][3];
+  unsigned paint;  // bit k set -> class k is painted
+};
+__global__ __launch_bounds__(256) void overlay_u8_k(const unsigned char* __restrict__ frames, int hs, int ws,
+                                                    const float* __restrict__ probs, int ncls, int h, int w,
+                                                    OverlayColors col, unsigned char* __restrict__ out,
+                                                    unsigned char* __restrict__ pred_out) {
+  const int n = blockIdx.y;
+  const int px = blockIdx.x * 256 + threadIdx.x;
+  if (px >= h * w) return;
+  const long long hw = (long long)h * w;
+  const float* pr = probs + (long long)n * ncls * hw + px;
+  int best = 0;
+  float bv = pr[0];
+  for (int k = 1; k < ncls; ++k) {
+    const float v = pr[k * hw];
+    if (v > bv) {
+      bv = v;
+      best = k;
+    }
+  }
+  if (pred_out) pred_out[(long long)n * hw + px] = (unsigned char)best;
+  unsigned char* o = out + ((long long)n * hw + px) * 3;
+  if ((col.paint >> best) & 1u) {
+    o[0] = col.bgr[best][0];
+    o[1] = col.bgr[best][1];
+    o[2] = col.bgr[best][2];
+    return;
+  }
+  const int dy = px / w, dx = px - dy * w;
+  int x0, x1, a0, a1, y0, y1, b0, b1;
+  lin_coef(dx, w, ws, &x0, &x1, &a0, &a1);
+  lin_coef(dy, h, hs, &y0, &y1, &b0, &b1);
+  const unsigned char* f = frames + (long long)n * hs * ws * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int r0 = f[((long long)y0 * ws + x0) * 3 + c] * a0 + f[((long long)y0 * ws + x1) * 3 + c] * a1;
+    const int r1 = f[((long long)y1 * ws + x0) * 3 + c] * a0 + f[((long long)y1 * ws + x1) * 3 + c] * a1;
+    const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+    o[c] = (unsigned char)min(max(v, 0), 255);
+  }
+}
+
+int overlay_u8(const unsigned char* frames, int N, int hs, int ws, const float* probs, int ncls, int h, int w,
+               const unsigned char* colors_host, unsigned paint_mask, unsigned char* out, unsigned char* pred_out,
+               hipStream_t s) {
+  OverlayColors col;
+  memset(&col, 0, sizeof(col));
+  for (int k = 0; k < ncls && k < 16; ++k)
+    for (int c = 0; c < 3; ++c) col.bgr[k][c] = colors_host[k * 3 + c];
+  col.paint = paint_mask;
+  dim3 grid((unsigned)((h * w + 255) / 256), (unsigned)N);
+  hipLaunchKernelGGL(overlay_u8_k, grid, dim3(256), 0, s, frames, hs, ws, probs, ncls, h, w, col, out, pred_out);
   RLN_LAUNCH_CHECK();
 }
 
