@@ -85,6 +85,13 @@ int rln_feature_channels(const rln_ctx* ctx);
 int rln_num_dropouts(const rln_ctx* ctx);
 int64_t rln_dropout_channels(const rln_ctx* ctx, int* per_call /* may be NULL, else [num_dropouts] */);
 
+/* Arithmetic of the DenseLayer 3x3 convolutions (86 % of the path's FLOPs).  Storage is fp32 in every mode.
+ *   parts = 0 : exact fp32 MFMA (v_mfma_f32_16x16x4_f32), the round-1 kernels;
+ *   parts = 1..3 : 16-bit MFMA on operands split into `parts` bf16 (dtype 0) / f16 (dtype 1) parts, fp32 accumulate
+ *                  (csrc/dense3.h; 2 parts = 3 products ~ 2^-17 (bf16) / 2^-22 (f16), 3 bf16 parts = 6 products < fp32 eps).
+ * fwd_* selects the forward kernels, bwd_* the data / weight gradient kernels.  Call before rln_workspace_bytes. */
+int rln_set_dense_arith(rln_ctx* ctx, int fwd_parts, int fwd_dtype, int bwd_parts, int bwd_dtype);
+
 int rln_bind_params(rln_ctx* ctx, float* params, float* grads, float* bn_running, int64_t* num_batches_tracked);
 
 /* ---- workspace -------------------------------------------------------------------------
@@ -150,6 +157,14 @@ int rln_op_conv_bnrelu(const float* x, int n, int cin, int x_ctot, int x_coff, i
                        const float* b, const float* weight, const float* bias, int cout, int ksize,
                        const float* scale, float* out, int out_ctot, int out_coff, int pool, uint8_t* pool_idx,
                        float* stats, void* workspace, size_t workspace_bytes, void* stream);
+/* rln_op_dense3_fwd: the same dense-layer forward (ksize 3, cout <= 16, folded affine required) on the 16-bit MFMA pipe
+ * with split fp32 operands (csrc/dense3.h): parts = 1..3 operand parts, dtype 0 = bf16, 1 = f16.  workspace holds the
+ * packed weight fragments and the statistics partials.  Returns RLN_ERR_UNSUPPORTED for geometries the kernel does
+ * not cover (W % 4 != 0, W < 40, unaligned views): callers fall back to rln_op_conv_bnrelu (exact fp32 MFMA). */
+int rln_op_dense3_fwd(const float* x, int n, int cin, int x_ctot, int x_coff, int h, int w, const float* a,
+                      const float* b, const float* weight, const float* bias, int cout, const float* scale, float* out,
+                      int out_ctot, int out_coff, float* stats, int parts, int dtype, void* workspace,
+                      size_t workspace_bytes, void* stream);
 /* rln_op_convt: ConvTranspose2d(k3,s2,p0)+bias cropped top-left to (hout,wout) (layers.py:58-67,82-86). */
 int rln_op_convt(const float* x, int n, int cin, int h, int w, const float* weight, const float* bias, int cout,
                  float* out, int out_ctot, int out_coff, int hout, int wout, void* stream);

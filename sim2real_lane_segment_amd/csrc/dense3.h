@@ -1,0 +1,63 @@
+// Dense-block 3x3 family on the 16-bit MFMA pipe (v_mfma_f32_16x16x32_{bf16,f16}) with fp32 storage.
+//
+// The DenseLayer convolutions of the path (layers.py:8-12: BN -> ReLU -> Conv2d(Cin,16,3) -> Dropout2d) are GEMMs
+// with N = 16 output channels.  On the exact-fp32 MFMA (1/16 of the 16-bit rate) they are matrix-pipe bound; here every
+// fp32 operand is split on the fly into NP 16-bit parts (x = x0 + x1 (+ x2), each part the rounding of the remainder)
+// and the product is assembled from the leading cross terms, accumulated in fp32 inside the MFMA:
+//   NP = 1: x0*w0                               (plain 16-bit operands: the bf16 throughput mode)
+//   NP = 2: x0*w0 + x0*w1 + x1*w0               (bf16: ~2^-17 relative per term; f16: ~2^-22)
+//   NP = 3: + x0*w2 + x1*w1 + x2*w0             (bf16: ~2^-25, below fp32 rounding)
+// so the kernels become HBM-bound: activations stay fp32 NCHW in HBM, are read once per launch, transposed to a
+// [pixel][channel] image in LDS while BN+ReLU is applied, and fed to the MFMA as 8-channel (16-byte) fragments.
+#pragma once
+#include "common.h"
+
+namespace rln {
+
+enum { D3_BF16 = 0, D3_F16 = 1 };
+
+// ---- weight packing ---------------------------------------------------------------------------------------------
+// One descriptor per dense layer; the pack kernel converts W[Cout][Cin][3][3] (fp32, parameter arena) into MFMA
+// B-operand fragments, once per forward (the optimiser changes the weights every step):
+//   forward  orientation  wf[chunk][s][part][lane] : n = lane&15 = output channel, k = 8*(lane>>4)+e,
+//                          tap = 2s + (k>>4), input channel = 16*chunk + (k&15), value W[n][ch][tap]
+//   backward orientation  wb[cgroup][s][part][lane]: n = lane&15 -> input channel 16*cgroup + n, k as above,
+//                          tap' = 2s + (k>>4), o = k&15, value W[o][c][8 - tap']   (flipped taps)
+// each entry 8 halfwords (16 bytes); taps >= 9 and out-of-range channels are zero.
+struct D3PackDesc {
+  long long w_off;      // into the parameter arena (floats)
+  int cin, cout;
+  long long wf_off;     // into the packed buffer (uint4 units); -1: skip
+  long long wb_off;     // -1: skip
+  int unit_begin;       // first (chunk|cgroup, s) unit of this layer in the flat unit list
+  int n_units;          // 5 * ceil(cin/16) * (forward + backward)
+};
+inline long long d3_pack_entries(int cin, int np) { return (long long)((cin + 15) / 16) * 5 * np * 64; }
+int d3_pack_weights(const float* params, const D3PackDesc* desc_dev, int n_desc, int total_units, uint4* packed,
+                    int np, int dt, hipStream_t s);
+
+// ---- forward ----------------------------------------------------------------------------------------------------
+struct D3Fwd {
+  const float* S;  // input view: channel 0 of the layer's input range, [N][.][H][W]
+  long long ns;    // sample stride (floats)
+  int cs;          // channel (plane) stride
+  int H, W, Cin;
+  const float* pa;  // BN folded scale / shift [Cin]
+  const float* pb;
+  const uint4* wpk;  // forward-orientation fragments of this layer
+  const float* bias;    // [Cout]
+  const float* nscale;  // [N][Cout] Dropout2d scale or null
+  float* out;           // output view (channel 0 of the 16 new channels)
+  long long out_ns;
+  int out_cs, Cout;
+  float* stat_partial;  // [N*tiles][Cout][2] or null
+  int th, tw, tiles_x, tiles_y;
+  int ksplit;           // >1: raw partial sums to out + split*split_stride (no bias / scale / statistics)
+  long long split_stride;
+};
+// true when the launch geometry is supported (W % 4 == 0, 16-byte aligned planes, W >= 40, Cout <= 16)
+bool d3_fwd_supported(const D3Fwd& p);
+void d3_fwd_pick_tile(int H, int W, int* th, int* tw);
+int d3_fwd_launch(const D3Fwd& p, int N, int np, int dt, hipStream_t s);
+
+}  // namespace rln

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/rln.h"
+#include "dense3.h"
 #include "igemm.h"
 #include "pointwise.h"
 
@@ -159,6 +160,14 @@ struct rln_ctx {
   int loss_mode = 0;      // 0: weighted CE (rln_loss), 1: entropy with gradient reversal (rln_entropy_loss)
   float loss_lamda = 0.f;
   const float* last_scales = nullptr;
+  // dense-layer arithmetic (rln_set_dense_arith): 0 parts = exact fp32 MFMA kernels, else split 16-bit MFMA (dense3.h)
+  int d3_fwd_np = 0, d3_fwd_dt = 0, d3_bwd_np = 0, d3_bwd_dt = 0;
+  std::vector<D3PackDesc> d3_desc_f, d3_desc_b;  // host copies, one entry per dense op
+  std::vector<long long> d3_wf_off, d3_wb_off;   // per op index (uint4 units into d3_packed), -1: none
+  D3PackDesc* d3_desc_f_dev = nullptr;
+  D3PackDesc* d3_desc_b_dev = nullptr;
+  uint4* d3_packed = nullptr;
+  int d3_units_f = 0, d3_units_b = 0;
 };
 
 namespace {
@@ -468,6 +477,11 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
       igemm_tile_dims(IG_CONV3_BN, tile, &th, &tw);
       const size_t blocks = (size_t)n * ((Hd + th - 1) / th) * ((Wd + tw - 1) / tw);
       stat_max = std::max(stat_max, blocks * o.cout * 2);
+      if (o.type == OP_DENSE && c->d3_fwd_np > 0) {
+        int dth, dtw;
+        d3_fwd_pick_tile(Hd, Wd, &dth, &dtw);
+        stat_max = std::max(stat_max, (size_t)n * ((Hd + dth - 1) / dth) * ((Wd + dtw - 1) / dtw) * o.cout * 2);
+      }
       if (o.type == OP_DENSE) {
         const int sp = dense_fwd_split(Hd * Wd, o.cin);
         if (sp > 1) {
@@ -540,6 +554,41 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
   float* wpartial = with_bwd ? cv.take<float>(wp_max) : nullptr;
   float* bpartial = with_bwd ? cv.take<float>(bp_max) : nullptr;
   float* glin = with_bwd ? cv.take<float>((size_t)n * c->cfg.n_classes * hw0) : nullptr;
+  // split-operand dense kernels: packed weight fragments + descriptor tables
+  std::vector<D3PackDesc> dfh, dbh;
+  std::vector<long long> wf_off(c->ops.size(), -1), wb_off(c->ops.size(), -1);
+  long long pk_total = 0;
+  int units_f = 0, units_b = 0;
+  for (size_t k = 0; k < c->ops.size(); ++k) {
+    const Op& o = c->ops[k];
+    if (o.type != OP_DENSE || o.cout > 16) continue;
+    D3PackDesc d;
+    d.w_off = o.conv.w;
+    d.cin = o.cin;
+    d.cout = o.cout;
+    d.n_units = 5 * ((o.cin + 15) / 16);
+    if (c->d3_fwd_np > 0) {
+      d.wf_off = pk_total;
+      d.wb_off = -1;
+      d.unit_begin = units_f;
+      wf_off[k] = pk_total;
+      pk_total += d3_pack_entries(o.cin, c->d3_fwd_np);
+      units_f += d.n_units;
+      dfh.push_back(d);
+    }
+    if (c->d3_bwd_np > 0 && with_bwd) {
+      d.wf_off = -1;
+      d.wb_off = pk_total;
+      d.unit_begin = units_b;
+      wb_off[k] = pk_total;
+      pk_total += d3_pack_entries(o.cin, c->d3_bwd_np);
+      units_b += d.n_units;
+      dbh.push_back(d);
+    }
+  }
+  uint4* d3_packed = cv.take<uint4>((size_t)pk_total);
+  D3PackDesc* d3_df = cv.take<D3PackDesc>(dfh.size());
+  D3PackDesc* d3_db = cv.take<D3PackDesc>(dbh.size());
   int* lcounts = cv.take<int>(32 + 256);
   float* lpartial = cv.take<float>((size_t)loss_blocks((long long)n * hw0) * 4);
   float* lresult = cv.take<float>(64);
@@ -568,6 +617,15 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
     c->wpartial = wpartial;
     c->bpartial = bpartial;
     c->glin = glin;
+    c->d3_desc_f = dfh;
+    c->d3_desc_b = dbh;
+    c->d3_wf_off = wf_off;
+    c->d3_wb_off = wb_off;
+    c->d3_packed = d3_packed;
+    c->d3_desc_f_dev = d3_df;
+    c->d3_desc_b_dev = d3_db;
+    c->d3_units_f = units_f;
+    c->d3_units_b = units_b;
     c->loss.counts = lcounts;
     c->loss.partial = lpartial;
     c->loss.result = lresult;
@@ -731,6 +789,42 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
     }
     p.GH = (dl.H + 1) / 2;
     p.GW = (dl.W + 1) / 2;
+  }
+  if (o.type == OP_DENSE && c->d3_fwd_np > 0 && c->d3_wf_off[k] >= 0) {  // split-operand 16-bit MFMA kernel
+    D3Fwd q;
+    memset(&q, 0, sizeof(q));
+    q.S = p.in;
+    q.ns = p.in_ns;
+    q.cs = p.in_cs;
+    q.H = dl.H;
+    q.W = dl.W;
+    q.Cin = o.cin;
+    q.pa = p.pa;
+    q.pb = p.pb;
+    q.wpk = c->d3_packed + c->d3_wf_off[k];
+    q.bias = p.bias;
+    q.nscale = p.nscale;
+    q.out = p.out;
+    q.out_ns = p.out_ns;
+    q.out_cs = p.out_cs;
+    q.Cout = o.cout;
+    q.stat_partial = p.stat_partial;
+    q.ksplit = 1;
+    if (d3_fwd_supported(q)) {
+      d3_fwd_pick_tile(q.H, q.W, &q.th, &q.tw);
+      q.tiles_y = (q.H + q.th - 1) / q.th;
+      q.tiles_x = (q.W + q.tw - 1) / q.tw;
+      {
+        const double flops = 2.0 * o.cin * o.cout * 9.0 * q.H * q.W * N;
+        const double bytes = 4.0 * N * ((double)o.cin + o.cout) * q.H * q.W;
+        ProfScope ps(c, PC_DENSE_FWD, flops, bytes, s);
+        RLN_TRY(d3_fwd_launch(q, N, c->d3_fwd_np, c->d3_fwd_dt, s));
+      }
+      if (training)
+        RLN_TRY(finalize_stats(c, o.dst_level, o.out_off, o.cout, (long long)N * q.tiles_x * q.tiles_y, s,
+                               (long long)k));
+      return 0;
+    }
   }
   tile = igemm_pick_tile(p.GH, p.GW);
   if (kind == IG_CONV3_BN && igemm_pick_strip_tile(p.GW) >= 0 && aligned16(p.in) && (p.in_cs % 4) == 0 &&
@@ -1245,6 +1339,19 @@ int rln_tensor_info(const rln_ctx* c, int idx, char* name, int name_cap, int* ki
   return 0;
 }
 
+int rln_set_dense_arith(rln_ctx* c, int fwd_parts, int fwd_dtype, int bwd_parts, int bwd_dtype) {
+  auto bad = [](int np, int dt) { return np < 0 || np > 3 || dt < 0 || dt > 1 || (dt == 1 && np == 3); };
+  if (bad(fwd_parts, fwd_dtype) || bad(bwd_parts, bwd_dtype))
+    return fail(RLN_ERR_ARG, "parts in 0..3 (f16: 0..2), dtype 0 (bf16) or 1 (f16)");
+  c->d3_fwd_np = fwd_parts;
+  c->d3_fwd_dt = fwd_dtype;
+  c->d3_bwd_np = bwd_parts;
+  c->d3_bwd_dt = bwd_dtype;
+  c->levels[0].S = nullptr;  // the workspace layout depends on the mode: it has to be set again
+  c->N = c->H = c->W = 0;
+  return 0;
+}
+
 int rln_bind_params(rln_ctx* c, float* params, float* grads, float* bn_running, int64_t* nbt) {
   if (!params || !bn_running) return fail(RLN_ERR_ARG, "params and bn_running are required");
   c->params = params;
@@ -1267,6 +1374,16 @@ int rln_set_workspace(rln_ctx* c, void* ws, size_t bytes, int n, int h, int w, i
   if (!ws || bytes < need) return fail(RLN_ERR_WORKSPACE, "workspace of %zu bytes needed, got %zu", need, bytes);
   if (((uintptr_t)ws) & 255) return fail(RLN_ERR_WORKSPACE, "workspace must be 256-byte aligned");
   carve(c, ws, n, h, w, with_backward, true);
+  if (!c->d3_desc_f.empty() || !c->d3_desc_b.empty()) {  // descriptor tables of the weight-pack kernel (setup time)
+    hipError_t e = hipSuccess;
+    if (!c->d3_desc_f.empty())
+      e = hipMemcpy(c->d3_desc_f_dev, c->d3_desc_f.data(), c->d3_desc_f.size() * sizeof(D3PackDesc),
+                    hipMemcpyHostToDevice);
+    if (e == hipSuccess && !c->d3_desc_b.empty())
+      e = hipMemcpy(c->d3_desc_b_dev, c->d3_desc_b.data(), c->d3_desc_b.size() * sizeof(D3PackDesc),
+                    hipMemcpyHostToDevice);
+    if (e != hipSuccess) return fail((int)e, "descriptor upload failed");
+  }
   c->N = n;
   c->H = h;
   c->W = w;
@@ -1294,6 +1411,12 @@ int rln_forward(rln_ctx* c, const float* x, int n, int h, int w, int training, c
     if (c->nbt) RLN_TRY(add_one_i64((long long*)c->nbt, c->n_nbt, s));
   }
   c->prep_done = -1;
+  if (c->d3_units_f > 0)
+    RLN_TRY(d3_pack_weights(c->params, c->d3_desc_f_dev, (int)c->d3_desc_f.size(), c->d3_units_f, c->d3_packed,
+                            c->d3_fwd_np, c->d3_fwd_dt, s));
+  if (c->d3_units_b > 0 && training && c->with_bwd)
+    RLN_TRY(d3_pack_weights(c->params, c->d3_desc_b_dev, (int)c->d3_desc_b.size(), c->d3_units_b, c->d3_packed,
+                            c->d3_bwd_np, c->d3_bwd_dt, s));
   for (size_t k = 0; k < c->ops.size(); ++k) RLN_TRY(fwd_op(c, k, x, training, s));
   if (probs_out || feat_out) {
     HeadParams hp = head_params(c);
@@ -1480,6 +1603,64 @@ int rln_op_conv_bnrelu(const float* x, int n, int cin, int x_ctot, int x_coff, i
   }
   RLN_TRY(igemm_launch(kind, tile, p, n, s));
   if (stats) RLN_TRY(reduce_rows(p.stat_partial, nblk, (long long)cout * 2, stats, s));
+  return 0;
+}
+
+int rln_op_dense3_fwd(const float* x, int n, int cin, int x_ctot, int x_coff, int h, int w, const float* a,
+                      const float* b, const float* weight, const float* bias, int cout, const float* scale, float* out,
+                      int out_ctot, int out_coff, float* stats, int parts, int dtype, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!x || !a || !b || !weight || !out || !workspace) return fail(RLN_ERR_ARG, "null pointer");
+  if (parts < 1 || parts > 3 || dtype < 0 || dtype > 1 || (dtype == 1 && parts == 3))
+    return fail(RLN_ERR_ARG, "parts in 1..3 (f16: 1..2), dtype 0 (bf16) or 1 (f16)");
+  const size_t plane = (size_t)h * w;
+  D3Fwd p;
+  memset(&p, 0, sizeof(p));
+  p.S = x + (size_t)x_coff * plane;
+  p.ns = (long long)x_ctot * plane;
+  p.cs = (int)plane;
+  p.H = h;
+  p.W = w;
+  p.Cin = cin;
+  p.pa = a;
+  p.pb = b;
+  p.bias = bias;
+  p.nscale = scale;
+  p.out = out + (size_t)out_coff * plane;
+  p.out_ns = (long long)out_ctot * plane;
+  p.out_cs = (int)plane;
+  p.Cout = cout;
+  p.ksplit = 1;
+  if (!d3_fwd_supported(p)) return fail(RLN_ERR_UNSUPPORTED, "geometry not covered by the dense3 forward kernel");
+  d3_fwd_pick_tile(h, w, &p.th, &p.tw);
+  p.tiles_y = (h + p.th - 1) / p.th;
+  p.tiles_x = (w + p.tw - 1) / p.tw;
+  // workspace: [descriptor | packed weights | statistics partials]
+  Carver cv(workspace);
+  D3PackDesc* desc = cv.take<D3PackDesc>(1);
+  const long long entries = d3_pack_entries(cin, parts);
+  uint4* packed = cv.take<uint4>((size_t)entries);
+  const long long nblk = (long long)n * p.tiles_x * p.tiles_y;
+  float* partial = stats ? cv.take<float>((size_t)nblk * cout * 2) : nullptr;
+  if (cv.off > workspace_bytes) return fail(RLN_ERR_WORKSPACE, "workspace of %zu bytes needed", cv.off);
+  // the weight may live anywhere: describe it relative to itself
+  D3PackDesc d;
+  d.w_off = 0;
+  d.cin = cin;
+  d.cout = cout;
+  d.wf_off = 0;
+  d.wb_off = -1;
+  d.unit_begin = 0;
+  d.n_units = 5 * ((cin + 15) / 16);
+  hipError_t e = hipMemcpyAsync(desc, &d, sizeof(d), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);  // `d` is a stack object
+  if (e != hipSuccess) return fail((int)e, "descriptor upload failed");
+  RLN_TRY(d3_pack_weights(weight, desc, 1, d.n_units, packed, parts, dtype, s));
+  p.wpk = packed;
+  p.stat_partial = partial;
+  RLN_TRY(d3_fwd_launch(p, n, parts, dtype, s));
+  if (stats) RLN_TRY(reduce_rows(partial, nblk, (long long)cout * 2, stats, s));
   return 0;
 }
 

@@ -141,6 +141,18 @@ class Engine:
     def state(self) -> Dict[str, torch.Tensor]:
         return {m.name: self.views[m.name].detach().clone() for m in self.metas}
 
+    # ---- arithmetic of the dense 3x3 layers -------------------------------------------------
+    DTYPES = {"bf16": 0, "f16": 1}
+
+    def set_dense_arith(self, fwd_parts=0, fwd_dtype="bf16", bwd_parts=0, bwd_dtype="bf16"):
+        """0 parts = exact fp32 MFMA kernels; 1..3 = 16-bit MFMA on operands split into that many parts
+        (rln_set_dense_arith, include/rln.h).  Storage stays fp32 in every mode."""
+        _lib.check(self.L.rln_set_dense_arith(self.ctx, int(fwd_parts), self.DTYPES[fwd_dtype], int(bwd_parts),
+                                              self.DTYPES[bwd_dtype]), "rln_set_dense_arith")
+        self.dense_arith = (int(fwd_parts), fwd_dtype, int(bwd_parts), bwd_dtype)
+        self._ws = None
+        self._ws_key = None
+
     # ---- workspace ------------------------------------------------------------------------
     def _require_gpu(self):
         if self.device.type != "cuda":

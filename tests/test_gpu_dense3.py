@@ -1,0 +1,73 @@
+"""Split-operand 16-bit MFMA dense kernels (csrc/dense3.*) through the C ABI against plain PyTorch CPU operators
+(fp64 reference for the error figures, fp32 tolerance stated per mode)."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from sim2real_lane_segment_amd import _lib as L
+    return L, L.lib()
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# relative-to-max error bars per (parts, dtype): one rounding of a 16-bit part costs 2^-9 (bf16) / 2^-12 (f16)
+TOL = {(1, 0): 2e-2, (2, 0): 1e-4, (3, 0): 3e-6, (1, 1): 3e-3, (2, 1): 3e-6}
+
+
+@pytest.mark.parametrize("h,w", [(8, 40), (16, 80), (30, 40), (24, 160), (13, 44), (60, 80), (9, 96), (33, 120)])
+@pytest.mark.parametrize("cin,cout", [(48, 16), (80, 16), (52, 12), (272, 16)])
+@pytest.mark.parametrize("parts,dtype", [(2, 0), (3, 0), (2, 1), (1, 0)])
+def test_dense3_forward(h, w, cin, cout, parts, dtype):
+    if cin == 272 and (h, w) not in [(16, 80), (24, 160)]:
+        pytest.skip("large-K case runs on two geometries")
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(h * 1000 + w + cin + parts)
+    n, x_ctot, x_coff, out_ctot, out_coff = 2, cin + 12, 4, cout + 8, 4
+    x = torch.randn(n, x_ctot, h, w, generator=g)
+    a = torch.rand(cin, generator=g) + 0.5
+    b = torch.randn(cin, generator=g) * 0.3
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    bias = torch.randn(cout, generator=g) * 0.1
+    scale = (torch.rand(n, cout, generator=g) < 0.8).float() * 1.25
+    xin = x[:, x_coff:x_coff + cin]
+    z = F.relu(xin * a[None, :, None, None] + b[None, :, None, None])
+    ref = (F.conv2d(z.double(), wt.double(), bias.double(), padding=1) * scale[:, :, None, None].double())
+    dev = "cuda"
+    out = torch.full((n, out_ctot, h, w), 7.0, device=dev)
+    stats = torch.zeros(cout, 2, device=dev)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    xd, wd, bd, sd, ad, bbd = (t.to(dev) for t in (x, wt, bias, scale, a, b))
+    L.check(lib.rln_op_dense3_fwd(_p(xd), n, cin, x_ctot, x_coff, h, w, _p(ad), _p(bbd), _p(wd), _p(bd), cout, _p(sd),
+                                  _p(out), out_ctot, out_coff, _p(stats), parts, dtype, _p(ws), ws.numel(), _stream()))
+    torch.cuda.synchronize()
+    got = out.cpu()
+    err = float((got[:, out_coff:out_coff + cout].double() - ref).abs().max()) / float(ref.abs().max())
+    assert err < TOL[(parts, dtype)], err
+    assert torch.all(got[:, :out_coff] == 7.0) and torch.all(got[:, out_coff + cout:] == 7.0)
+    s = stats.cpu().double()
+    gsel = got[:, out_coff:out_coff + cout].double()
+    assert torch.allclose(s[:, 0], gsel.sum((0, 2, 3)), atol=1e-3, rtol=1e-4)
+    assert torch.allclose(s[:, 1], (gsel * gsel).sum((0, 2, 3)), atol=1e-3, rtol=1e-4)
+
+
+def test_dense3_unsupported_geometry_is_reported():
+    L, lib = _lib()
+    x = torch.zeros(1, 16, 7, 10, device="cuda")
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
+    o = torch.zeros(1, 16, 7, 10, device="cuda")
+    v = torch.zeros(16 * 16 * 9, device="cuda")
+    rc = lib.rln_op_dense3_fwd(_p(x), 1, 16, 16, 0, 7, 10, _p(v), _p(v), _p(v), _p(v), 16, None, _p(o), 16, 0, None, 2, 0,
+                               _p(ws), ws.numel(), _stream())
+    assert rc == -4
