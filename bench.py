@@ -182,6 +182,8 @@ def main():
                     help="engine: TrainStepper (direct C-ABI calls, overlapped all-reduce); module: the reference-shaped "
                          "path training_step -> loss.backward() -> optimizer.step() (what Lightning drives)")
     ap.add_argument("--no-module-api", action="store_true", help="skip the secondary module-API timing")
+    ap.add_argument("--fwd-arith", default=None, help="dense 3x3 forward arithmetic: fp32 | bf16x1..3 | f16x1..2")
+    ap.add_argument("--bwd-arith", default=None, help="dense 3x3 backward arithmetic: fp32 | bf16x1..3 | f16x1..2")
     args = ap.parse_args()
 
     env_world = os.environ.get("WORLD_SIZE")
@@ -219,6 +221,15 @@ def main():
     model = SimpleTrainModule(lr=1e-3, lrRatio=1e3, decay=1e-4, num_cls=4).to(dev)  # random init, FCDenseNet67
     model.train()
     eng = model._rln_sync()
+    if args.fwd_arith or args.bwd_arith:
+        def parse(a):
+            if a in (None, "fp32"):
+                return 0, "bf16"
+            t, n = a.split("x")
+            return int(n), t
+        fp, ft = parse(args.fwd_arith)
+        bp, bt = parse(args.bwd_arith)
+        eng.set_dense_arith(fp, ft, bp, bt)
     stepper = TrainStepper(eng, lr=1e-3, weight_decay=1e-4, n_buckets=args.buckets, force_collectives=args.force_dist)
     stepper.broadcast_parameters()
     if dist.is_initialized() and dist.get_world_size() != world:

@@ -52,12 +52,14 @@ struct D3Fwd {
   int out_cs, Cout;
   float* stat_partial;  // [N*tiles][Cout][2] or null
   int th, tw, tiles_x, tiles_y;
+  int rg;               // rows per staging lane group (2 or 4), from d3_fwd_pick_tile
   int ksplit;           // >1: raw partial sums to out + split*split_stride (no bias / scale / statistics)
   long long split_stride;
+  int dbg;              // diagnostic builds (-DRLN_DIAG) only: 1 no global loads, 2 no commit, 4 no MFMA phase, 8 no zero-init
 };
 // true when the launch geometry is supported (W % 4 == 0, 16-byte aligned planes, W >= 40, Cout <= 16)
 bool d3_fwd_supported(const D3Fwd& p);
-void d3_fwd_pick_tile(int H, int W, int* th, int* tw);
+void d3_fwd_pick_tile(int H, int W, int np, int* th, int* tw, int* rg);
 int d3_fwd_launch(const D3Fwd& p, int N, int np, int dt, hipStream_t s);
 
 }  // namespace rln

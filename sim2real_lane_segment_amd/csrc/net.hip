@@ -478,8 +478,8 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
       const size_t blocks = (size_t)n * ((Hd + th - 1) / th) * ((Wd + tw - 1) / tw);
       stat_max = std::max(stat_max, blocks * o.cout * 2);
       if (o.type == OP_DENSE && c->d3_fwd_np > 0) {
-        int dth, dtw;
-        d3_fwd_pick_tile(Hd, Wd, &dth, &dtw);
+        int dth, dtw, drg;
+        d3_fwd_pick_tile(Hd, Wd, c->d3_fwd_np, &dth, &dtw, &drg);
         stat_max = std::max(stat_max, (size_t)n * ((Hd + dth - 1) / dth) * ((Wd + dtw - 1) / dtw) * o.cout * 2);
       }
       if (o.type == OP_DENSE) {
@@ -811,7 +811,7 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
     q.stat_partial = p.stat_partial;
     q.ksplit = 1;
     if (d3_fwd_supported(q)) {
-      d3_fwd_pick_tile(q.H, q.W, &q.th, &q.tw);
+      d3_fwd_pick_tile(q.H, q.W, c->d3_fwd_np, &q.th, &q.tw, &q.rg);
       q.tiles_y = (q.H + q.th - 1) / q.th;
       q.tiles_x = (q.W + q.tw - 1) / q.tw;
       {
@@ -1633,7 +1633,7 @@ int rln_op_dense3_fwd(const float* x, int n, int cin, int x_ctot, int x_coff, in
   p.Cout = cout;
   p.ksplit = 1;
   if (!d3_fwd_supported(p)) return fail(RLN_ERR_UNSUPPORTED, "geometry not covered by the dense3 forward kernel");
-  d3_fwd_pick_tile(h, w, &p.th, &p.tw);
+  d3_fwd_pick_tile(h, w, parts, &p.th, &p.tw, &p.rg);
   p.tiles_y = (h + p.th - 1) / p.th;
   p.tiles_x = (w + p.tw - 1) / p.tw;
   // workspace: [descriptor | packed weights | statistics partials]
@@ -1659,6 +1659,9 @@ int rln_op_dense3_fwd(const float* x, int n, int cin, int x_ctot, int x_coff, in
   RLN_TRY(d3_pack_weights(weight, desc, 1, d.n_units, packed, parts, dtype, s));
   p.wpk = packed;
   p.stat_partial = partial;
+#ifdef RLN_DIAG
+  if (getenv("RLN_D3_DBG")) p.dbg = atoi(getenv("RLN_D3_DBG"));
+#endif
   RLN_TRY(d3_fwd_launch(p, n, parts, dtype, s));
   if (stats) RLN_TRY(reduce_rows(partial, nblk, (long long)cout * 2, stats, s));
   return 0;
