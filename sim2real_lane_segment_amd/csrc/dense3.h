@@ -62,4 +62,73 @@ bool d3_fwd_supported(const D3Fwd& p);
 void d3_fwd_pick_tile(int H, int W, int np, int* th, int* tw, int* rg);
 int d3_fwd_launch(const D3Fwd& p, int N, int np, int dt, hipStream_t s);
 
+// ---- weight gradient -------------------------------------------------------------------------------------------------
+// dW[o][c][tap] = sum_{n,p} dY[n][o][p] * relu(a[c]*S[n][c][p+tap] + b[c]): a GEMM whose K dimension is the pixel axis.
+// Both operands are staged as the same split 16-bit [pixel][16 channels] LDS images the forward kernel uses (z with its
+// halo, dY without) and read through ds_read_b64_tr_b16 (hardware transpose), so tap shifts are whole 32-byte pixel
+// records.  A block owns ONE 16-channel chunk of z and a contiguous range of pixel tiles; its 9 tap accumulators stay in
+// registers over the whole range.  Blocks of the same range (different chunks) are placed on one XCD so the dY tiles
+// they all read come from that XCD's L2.
+struct D3Wgrad {
+  const float* S;  // layer input view (channel 0 of the input range)
+  long long ns;
+  int cs, H, W, Cin;
+  const float* pa;
+  const float* pb;
+  const float* dY;  // [N][Cout][H][W]
+  int Cout, N;
+  int th, tw, tiles_x, tiles_y;
+  int rg;
+  int nchunks, nranges;
+  float* partial;  // [nranges][Cout*Cin*9], layout [o][c][tap]
+};
+bool d3_wgrad_supported(const D3Wgrad& p);
+void d3_wgrad_plan(int H, int W, int N, int Cin, D3Wgrad* p);  // fills th, tw, tiles, rg, nchunks, nranges
+int d3_wgrad_launch(const D3Wgrad& p, int np, int dt, hipStream_t s);
+
+// ---- data gradient of a dense block's INPUT channels ("pull" form) ----------------------------------------------------
+// A DenseBlock's input channels [0, C) are consumed by every layer j of the block (layers.py:33,39).  Instead of one
+// read-S / read-modify-write-G pass per layer, one launch handles all (up to D3_LMAX) layers at once: the layers' dY
+// tiles are staged once per pixel tile as 16-bit [pixel][channel] images; for each 16-channel output group the
+// contributions  gz_j[c] = relu'_j[c] * (W_j^T (*) dY_j)[c]  are accumulated in registers over j and
+//   G[c] (+)= sum_j gamma_j[c] * gz_j[c]          is written ONCE,
+// together with the BatchNorm-backward sums (sum gz_j, sum gz_j * xhat) per (layer, channel).
+#define D3_LMAX 5
+struct D3Pull {
+  int nl;                         // layers in this launch (1..D3_LMAX)
+  const float* dY[D3_LMAX];       // [N][Cout][H][W] finalised output gradients of the layers
+  int Cout;
+  const uint4* wpk[D3_LMAX];      // backward-orientation weight fragments of each layer
+  const float* ea[D3_LMAX];       // BN folded scale / shift of layer j (ReLU mask), indexed by input channel
+  const float* eb[D3_LMAX];
+  const float* egamma[D3_LMAX];
+  const float* mean;              // level statistics at the block's first input channel
+  const float* invstd;
+  const float* S;                 // activation stack view at the block's first input channel
+  long long s_ns;
+  int cs;                         // plane stride (= H*W)
+  float* G;                       // gradient stack view (same geometry)
+  int C;                          // input channels to produce
+  int acc_lo, acc_hi;             // channels in [acc_lo, acc_hi) accumulate into G, the others overwrite
+  int H, W, N;
+  int th, tw, tiles_x, tiles_y;
+  float* stat_partial;            // [2*blocks][nl][Cpad][2], Cpad = 16*ceil(C/16) (two rows per block)
+};
+bool d3_pull_supported(const D3Pull& p, int np);  // geometry + LDS budget (set nl, C, th, tw first)
+void d3_pull_pick_tile(int H, int W, int* th, int* tw);
+int d3_pull_blocks(const D3Pull& p);  // persistent grid size; stat_partial holds 2 rows per block
+int d3_pull_launch(const D3Pull& p, int np, int dt, hipStream_t s);
+// reduces the partial rows of a pull launch: dbeta_j[c] = sum gz_j, dgamma_j[c] = sum gz_j*xhat (c < C) and adds the
+// gamma-weighted sums of all layers into the level accumulators S1/S2 (fixed summation order)
+struct D3PullFin {
+  int nl, C, Cpad, rows;
+  const float* partial;  // [rows][nl][Cpad][2]
+  const float* gamma[D3_LMAX];
+  float* dgamma[D3_LMAX];
+  float* dbeta[D3_LMAX];
+  float* S1;
+  float* S2;
+};
+int d3_pull_finalize(const D3PullFin& f, hipStream_t s);
+
 }  // namespace rln

@@ -596,4 +596,728 @@ int d3_fwd_launch(const D3Fwd& p, int N, int np, int dt, hipStream_t s) {
   return -4;
 }
 
+// =============================================================================================
+// weight gradient (see dense3.h)
+//
+// 12 waves: waves 0-3 consume (wave w takes the 32-pixel K-steps w, w+4, w+8 of the 320-pixel tile: per K-step one dY
+// fragment and, per tap, one shifted z fragment through transposed LDS reads, 27 MFMAs at 2 parts); waves 4-7 / 8-11
+// are two producer groups taking alternate TILES (z chunk with BN+ReLU and halo + the dY tile, both split into 16-bit
+// parts), each re-issuing its global loads for tile i+3 right after committing tile i+1.  One barrier per tile.
+// =============================================================================================
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 lds_tr16(const unsigned char* p) {
+  union { s16x4 v; uint2 u; } c;
+  c.v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+  return c.u;
+}
+
+template <int NP, int DT>
+__global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave >= 4;
+  const int P = p.tw + 3;
+  const int rows = p.th + 2;
+  const int PLZ = rows * P * 32;          // one part of the z image
+  const int npix = p.th * p.tw;           // 320
+  const int PLY = npix * 32;              // one part of the dY image
+  const int ZB = NP * PLZ, YB = NP * PLY; // one buffer each
+  unsigned char* zbuf = smem;             // [2][NP][PLZ]
+  unsigned char* ybuf = smem + 2 * ZB;    // [2][NP][PLY]
+  float* abtab = reinterpret_cast<float*>(smem + 2 * ZB + 2 * YB);  // a[16], b[16] of this chunk
+
+  const unsigned lg_id = xcd_logical_block(blockIdx.x, gridDim.x);
+  const int chunk = (int)(lg_id % (unsigned)p.nchunks), range = (int)(lg_id / (unsigned)p.nchunks);
+  const int cb = min(chunk * 16, max(p.Cin - 16, 0));
+  const int tiles = p.tiles_x * p.tiles_y;
+  const int total = tiles * p.N;
+  const int per = (total + p.nranges - 1) / p.nranges;
+  const int t0 = range * per;
+  const int nt = max(0, min(total, t0 + per) - t0);
+
+  if (tid < 32) {
+    const int ch = cb + (tid & 15);
+    abtab[tid] = ch < p.Cin ? (tid < 16 ? p.pa[ch] : p.pb[ch]) : 0.f;
+  }
+
+  f32x4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (producer) {
+    const int pgroup = (wave - 4) >> 2;  // 0: tiles t0+1, +3, ...   1: tiles t0, +2, ...
+    const int ptid = tid & 255;
+    // z staging plan (tile-invariant part): lane-unit = 2 octets x RG rows x (4/RG) quads
+    const int nq = p.tw >> 2;
+    const int rgs = p.rg == 2 ? 1 : 2;
+    const int qpg = 4 >> rgs;
+    const int nqg = (nq + qpg - 1) / qpg;
+    const int nrg = (rows + p.rg - 1) >> rgs;
+    int z_r, z_q, z_o;
+    bool z_ex;
+    {
+      const int lu = ptid;
+      z_o = lu & 1;
+      const int rr = (lu >> 1) & (p.rg - 1), qq = (lu >> (1 + rgs)) & (qpg - 1), u = lu >> 3;
+      const int R = u / nqg;
+      z_q = (u - R * nqg) * qpg + qq;
+      z_r = (R << rgs) + rr;
+      z_ex = (R < nrg) && (z_r < rows) && (z_q < nq);
+    }
+    const int z_lds = ((z_ex ? z_r : 0) * P + 1 + 4 * (z_ex ? z_q : 0)) * 32 + z_o * 16;
+    // halo columns: (row, side, channel pair)
+    const int h_cp = ptid & 7, h_side = (ptid >> 3) & 1, h_r = ptid >> 4;
+    const bool h_ex = h_r < rows;
+    const int h_lds = ((h_ex ? h_r : 0) * P + (h_side ? p.tw + 1 : 0)) * 32 + h_cp * 4;
+    // dY staging: lane-unit = (octet, row-of-4-in-tile?, quad): 2 x th x nq units
+    const int y_o = ptid & 1, y_u = ptid >> 1;
+    const int y_r = y_u / nq, y_q = y_u - y_r * nq;
+    const bool y_ex = y_r < p.th;
+    const int y_lds = ((y_ex ? y_r : 0) * p.tw + 4 * y_q) * 32 + y_o * 16;
+
+    float4 zreg[8], yreg[8];
+    float hreg[2];
+    unsigned okbits = 0;  // validity of the in-flight tile: bit0 z unit, bit1 halo unit, bit2 dY unit
+    auto issue = [&](int t) __attribute__((always_inline)) {
+      const int n = t / tiles, tl = t - n * tiles;
+      const int tile_y = tl / p.tiles_x, tile_x = tl - tile_y * p.tiles_x;
+      const int gy0 = tile_y * p.th, gx0 = tile_x * p.tw;
+      const float* base = p.S + (long long)n * p.ns + (long long)cb * p.cs;
+      {
+        const int iy = gy0 - 1 + z_r, ix = gx0 + 4 * z_q;
+        const bool ok = z_ex && iy >= 0 && iy < p.H && ix < p.W;
+        const float* src = base + (long long)(z_o * 8) * p.cs + (ok ? iy * p.W + ix : 0);
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) zreg[cc] = *reinterpret_cast<const float4*>(src + (long long)cc * p.cs);
+        okbits = ok ? 1u : 0u;
+      }
+      {
+        const int iy = gy0 - 1 + h_r, ix = h_side ? gx0 + p.tw : gx0 - 1;
+        const bool ok = h_ex && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        const float* src = base + (long long)(2 * h_cp) * p.cs + (ok ? iy * p.W + ix : 0);
+        hreg[0] = src[0];
+        hreg[1] = src[p.cs];
+        okbits |= ok ? 2u : 0u;
+      }
+      {
+        const int iy = gy0 + y_r, ix = gx0 + 4 * y_q;
+        const bool ok = y_ex && iy < p.H && ix < p.W;
+        const float* src = p.dY + ((long long)n * p.Cout) * p.cs + (ok ? iy * p.W + ix : 0);
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) {
+          const int ch = min(y_o * 8 + cc, p.Cout - 1);
+          yreg[cc] = *reinterpret_cast<const float4*>(src + (long long)ch * p.cs);
+        }
+        okbits |= ok ? 4u : 0u;
+      }
+    };
+    auto commit = [&](int buf) __attribute__((always_inline)) {
+      unsigned char* zb = zbuf + buf * ZB;
+      unsigned char* yb = ybuf + buf * YB;
+      if (z_ex) {  // z: BN + ReLU, zero outside the picture
+        const float* ab = abtab + z_o * 8;
+        const bool ok = okbits & 1u;
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+          unsigned parts[4][NP];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float4 u0 = zreg[2 * k], u1 = zreg[2 * k + 1];
+            const float x0 = px == 0 ? u0.x : px == 1 ? u0.y : px == 2 ? u0.z : u0.w;
+            const float x1 = px == 0 ? u1.x : px == 1 ? u1.y : px == 2 ? u1.z : u1.w;
+            const float z0 = ok ? fmaxf(fmaf(ab[2 * k], x0, ab[16 + 2 * k]), 0.f) : 0.f;
+            const float z1 = ok ? fmaxf(fmaf(ab[2 * k + 1], x1, ab[16 + 2 * k + 1]), 0.f) : 0.f;
+            split2<DT, NP>(z0, z1, parts[k]);
+          }
+#pragma unroll
+          for (int pt = 0; pt < NP; ++pt)
+            *reinterpret_cast<uint4*>(zb + pt * PLZ + z_lds + px * 32) =
+                make_uint4(parts[0][pt], parts[1][pt], parts[2][pt], parts[3][pt]);
+        }
+      }
+      if (h_ex) {
+        const bool ok = okbits & 2u;
+        const float z0 = ok ? fmaxf(fmaf(abtab[2 * h_cp], hreg[0], abtab[16 + 2 * h_cp]), 0.f) : 0.f;
+        const float z1 = ok ? fmaxf(fmaf(abtab[2 * h_cp + 1], hreg[1], abtab[16 + 2 * h_cp + 1]), 0.f) : 0.f;
+        unsigned parts[NP];
+        split2<DT, NP>(z0, z1, parts);
+#pragma unroll
+        for (int pt = 0; pt < NP; ++pt) *reinterpret_cast<unsigned*>(zb + pt * PLZ + h_lds) = parts[pt];
+      }
+      if (y_ex) {  // dY: plain split, zero outside the picture and beyond Cout
+        const bool ok = okbits & 4u;
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+          unsigned parts[4][NP];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float4 u0 = yreg[2 * k], u1 = yreg[2 * k + 1];
+            float x0 = px == 0 ? u0.x : px == 1 ? u0.y : px == 2 ? u0.z : u0.w;
+            float x1 = px == 0 ? u1.x : px == 1 ? u1.y : px == 2 ? u1.z : u1.w;
+            if (!ok || y_o * 8 + 2 * k >= p.Cout) x0 = 0.f;
+            if (!ok || y_o * 8 + 2 * k + 1 >= p.Cout) x1 = 0.f;
+            split2<DT, NP>(x0, x1, parts[k]);
+          }
+#pragma unroll
+          for (int pt = 0; pt < NP; ++pt)
+            *reinterpret_cast<uint4*>(yb + pt * PLY + y_lds + px * 32) =
+                make_uint4(parts[0][pt], parts[1][pt], parts[2][pt], parts[3][pt]);
+        }
+      }
+    };
+    // iteration i (consumers multiply tile t0+i): the group with (i & 1) == pgroup commits tile i+1, re-issues i+3;
+    // group 1 also stages the first tile
+    __syncthreads();  // affine table
+    if (pgroup == 1) {
+      if (nt > 0) {
+        issue(t0);
+        commit(0);
+        if (nt > 2) issue(t0 + 2);
+      }
+      __syncthreads();
+      if (nt > 0) __syncthreads();
+      int i = 1;
+      for (; i + 3 < nt; i += 2) {
+        commit((i + 1) & 1);
+        issue(t0 + i + 3);
+        __syncthreads();
+        __syncthreads();
+      }
+      for (; i < nt; ++i) {
+        if (((i & 1) == 1) && i + 1 < nt) commit((i + 1) & 1);
+        __syncthreads();
+      }
+    } else {
+      if (nt > 1) issue(t0 + 1);
+      __syncthreads();
+      int i = 0;
+      for (; i + 3 < nt; i += 2) {
+        commit((i + 1) & 1);
+        issue(t0 + i + 3);
+        __syncthreads();
+        __syncthreads();
+      }
+      for (; i < nt; ++i) {
+        if (((i & 1) == 0) && i + 1 < nt) commit((i + 1) & 1);
+        __syncthreads();
+      }
+    }
+  } else {
+    // =========================== consumer waves ===========================
+    // transposed-read addressing: lane 4q+pp of 16-lane group g supplies pixel record (8g + q [+4]), bytes 8pp..8pp+7
+    // and receives channel (lane & 15) of those 4 pixels.  Odd groups take their two 4-pixel blocks in swapped order
+    // (bank-conflict-free halves); both operands use the same order, so the k pairing inside the MFMA is unchanged.
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    constexpr int KS = 3;  // K-steps per wave (tile of 320 pixels = 10 K-steps; waves 0,1 take 3, waves 2,3 take 2)
+    int ya[KS][2], za[KS][2];
+    int nks = 0;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      const int ks = wave + 4 * k;
+      if (ks * 32 < npix) nks = k + 1;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int blk = (h ^ (g & 1)) * 4;  // which 4-pixel block of the lane group's 8 pixels
+        const int pix = min(ks * 32 + 8 * g + blk + q, npix - 1);
+        ya[k][h] = pix * 32 + 8 * pp;
+        const int ty = pix / p.tw, tx = pix - ty * p.tw;
+        za[k][h] = ((ty + 1) * P + tx + 1) * 32 + 8 * pp;
+      }
+    }
+    __syncthreads();  // affine table
+    __syncthreads();  // first tile staged
+    for (int i = 0; i < nt; ++i) {
+      const unsigned char* zb = zbuf + (i & 1) * ZB;
+      const unsigned char* yb = ybuf + (i & 1) * YB;
+#pragma unroll
+      for (int k = 0; k < KS; ++k) {
+        if (k < nks) {
+          uint4 af[NP];
+#pragma unroll
+          for (int pt = 0; pt < NP; ++pt) {
+            const uint2 lo = lds_tr16(yb + pt * PLY + ya[k][0]), hi = lds_tr16(yb + pt * PLY + ya[k][1]);
+            af[pt] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          }
+          constexpr int DEPTH = 2, RING = DEPTH + 1;
+          uint4 bfr[RING][NP];
+#pragma unroll
+          for (int t = 0; t < DEPTH; ++t) {
+            const int toff = ((t / 3 - 1) * P + (t % 3 - 1)) * 32;
+#pragma unroll
+            for (int pt = 0; pt < NP; ++pt) {
+              const uint2 lo = lds_tr16(zb + pt * PLZ + za[k][0] + toff), hi = lds_tr16(zb + pt * PLZ + za[k][1] + toff);
+              bfr[t % RING][pt] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            if (t + DEPTH < 9) {
+              const int t1 = t + DEPTH;
+              const int toff = ((t1 / 3 - 1) * P + (t1 % 3 - 1)) * 32;
+#pragma unroll
+              for (int pt = 0; pt < NP; ++pt) {
+                const uint2 lo = lds_tr16(zb + pt * PLZ + za[k][0] + toff),
+                            hi = lds_tr16(zb + pt * PLZ + za[k][1] + toff);
+                bfr[t1 % RING][pt] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+              }
+            }
+            acc[t] = mfma_split<DT, NP>(af, bfr[t % RING], acc[t]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- reduce the four consumer waves' tap accumulators through LDS and write this block's slab piece ----
+  __syncthreads();
+  float4* red = reinterpret_cast<float4*>(smem);  // [4 waves][9 taps][64 lanes]
+  if (!producer) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) red[(wave * 9 + t) * 64 + lane] = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+  }
+  __syncthreads();
+  for (int e = tid; e < 9 * 64; e += 768) {
+    const int t = e >> 6, l = e & 63;
+    const float4 a0 = red[(0 * 9 + t) * 64 + l], a1 = red[(1 * 9 + t) * 64 + l], a2 = red[(2 * 9 + t) * 64 + l],
+                 a3 = red[(3 * 9 + t) * 64 + l];
+    const float v[4] = {a0.x + a1.x + a2.x + a3.x, a0.y + a1.y + a2.y + a3.y, a0.z + a1.z + a2.z + a3.z,
+                        a0.w + a1.w + a2.w + a3.w};
+    const int c = cb + (l & 15);  // D[row = 4*(l>>4) + r = output channel o][col = l & 15 = input channel]
+    if (c < p.Cin && c >= chunk * 16) {
+      float* dst = p.partial + (long long)range * p.Cout * p.Cin * 9;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = 4 * (l >> 4) + r;
+        if (o < p.Cout) dst[((long long)o * p.Cin + c) * 9 + t] = v[r];
+      }
+    }
+  }
+}
+
+bool d3_wgrad_supported(const D3Wgrad& p) {
+  if (p.Cout < 1 || p.Cout > 16 || p.Cin < 1) return false;
+  if ((p.W % 80) != 0 || p.H < 4) return false;
+  if ((p.cs & 3) || (p.ns & 3)) return false;
+  if ((reinterpret_cast<uintptr_t>(p.S) & 15) || (reinterpret_cast<uintptr_t>(p.dY) & 15)) return false;
+  return true;
+}
+
+void d3_wgrad_plan(int H, int W, int N, int Cin, D3Wgrad* p) {
+  p->th = 4;
+  p->tw = 80;
+  p->tiles_y = (H + 3) / 4;
+  p->tiles_x = (W + 79) / 80;
+  p->rg = 2;  // 6 staged rows = 3 bands of 2: one staging round of 240 lane-units
+  p->nchunks = (Cin + 15) / 16;
+  const long long total = (long long)p->tiles_x * p->tiles_y * N;
+  long long nr = std::max<long long>(1, 256 / p->nchunks);
+  nr = std::min(nr, total);
+  const long long per = (total + nr - 1) / nr;
+  p->nranges = (int)((total + per - 1) / per);  // no empty ranges
+}
+
+template <int NP, int DT>
+static int d3_wgrad_launch_t(const D3Wgrad& p, hipStream_t s) {
+  const int P = p.tw + 3, rows = p.th + 2;
+  const size_t lds = (size_t)2 * NP * rows * P * 32 + (size_t)2 * NP * p.th * p.tw * 32 + 128;
+  if (lds > 160 * 1024 || lds < 4 * 9 * 64 * 16) return -4;
+  auto kern = d3_wgrad_k<NP, DT>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    (void)hipGetLastError();
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.nchunks * p.nranges)), dim3(768), lds, s, p);
+  return (int)hipGetLastError();
+}
+
+int d3_wgrad_launch(const D3Wgrad& p, int np, int dt, hipStream_t s) {
+  if (!d3_wgrad_supported(p) || p.th != 4 || p.tw != 80 || p.rg != 2) return -4;
+  if (dt == D3_BF16) {
+    if (np == 1) return d3_wgrad_launch_t<1, D3_BF16>(p, s);
+    if (np == 2) return d3_wgrad_launch_t<2, D3_BF16>(p, s);
+    return d3_wgrad_launch_t<3, D3_BF16>(p, s);
+  }
+  if (np == 1) return d3_wgrad_launch_t<1, D3_F16>(p, s);
+  return d3_wgrad_launch_t<2, D3_F16>(p, s);
+}
+
+// =============================================================================================
+// data gradient, pull form (see dense3.h)
+//
+// Persistent blocks of 8 waves loop over pixel tiles of th x tw = 160 pixels (10 M-tiles).  Per tile: all waves stage
+// the nl dY tiles (+1 halo) as split 16-bit [pixel][16 channels] images (zero outside the picture); then every wave
+// walks its own output-channel groups (no barriers): per group it loads S (and G where it accumulates) for its 4
+// pixels x 10 M-tiles, and per layer runs 5 k-steps x 10 M-tiles of MFMAs (K = 16 output channels x 2 taps, flipped
+// weights), applies the layer's ReLU mask, adds gamma_j * gz_j to the running sum and the two BatchNorm-backward sums to
+// per-(layer, channel) slots in LDS.  G is written once per group.  Two waves per SIMD: one wave's epilogue VALU work
+// overlaps the other's MFMAs.
+// =============================================================================================
+template <int NP, int DT>
+__global__ __launch_bounds__(512, 2) void d3_pull_k(const D3Pull p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int MT = 5;  // M-tiles per work item: an item = (output-channel group, half of the 160-pixel tile)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lp = lane & 15, lg = lane >> 4;
+  const int P = p.tw + 3;
+  const int rows = p.th + 2;
+  const int PLANE = rows * P * 32;
+  const int LIMG = NP * PLANE;  // one layer's image
+  const int ngroups = (p.C + 15) >> 4;
+  const int Cpad = ngroups * 16;
+  float* stats = reinterpret_cast<float*>(smem + p.nl * LIMG);  // [half][nl][Cpad][2]
+  float* ctab = stats + 2 * p.nl * Cpad * 2;                     // [nl][Cpad][4]: ea, eb, gamma, - ; then [Cpad][2] mean, invstd
+  float* mtab = ctab + p.nl * Cpad * 4;
+  for (int i = tid; i < 2 * p.nl * Cpad * 2; i += 512) stats[i] = 0.f;
+  for (int i = tid; i < p.nl * Cpad; i += 512) {  // per-(layer, channel) constants: tile-invariant, read from LDS later
+    const int j = i / Cpad, ch = min(i - j * Cpad, p.C - 1);
+    ctab[i * 4 + 0] = p.ea[j][ch];
+    ctab[i * 4 + 1] = p.eb[j][ch];
+    ctab[i * 4 + 2] = p.egamma[j][ch];
+    ctab[i * 4 + 3] = 0.f;
+  }
+  for (int i = tid; i < Cpad; i += 512) {
+    mtab[i * 2 + 0] = p.mean[min(i, p.C - 1)];
+    mtab[i * 2 + 1] = p.invstd[min(i, p.C - 1)];
+  }
+
+  const int tiles = p.tiles_x * p.tiles_y;
+  const int total = tiles * p.N;
+  const int npix = p.th * p.tw;
+
+  // staging plan: lane-unit = (layer, 8-lane group: 2 channel octets x 4 rows, pixel quad); rounds over 512 threads
+  const int nq = p.tw >> 2;
+  const int nrb = (rows + 3) >> 2;
+  const int lul = 8 * nrb * nq;  // lane-units per layer
+  const int hul = rows * 16;     // halo units per layer: (row, side, channel pair)
+
+  int toff[5];
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    const int tap = min(2 * s + (lg >> 1), 8);
+    toff[s] = ((tap / 3 - 1) * P + (tap % 3 - 1)) * 32;
+  }
+
+  for (int t = blockIdx.x; t < total; t += gridDim.x) {
+    const int n = t / tiles, tl = t - n * tiles;
+    const int tile_y = tl / p.tiles_x, tile_x = tl - tile_y * p.tiles_x;
+    const int gy0 = tile_y * p.th, gx0 = tile_x * p.tw;
+    __syncthreads();  // previous tile's images are no longer read (also orders the stats zeroing)
+    // ---- stage the dY images (zero outside the picture and beyond Cout): all loads first, then convert ----
+    {
+      constexpr int NRD = 2;  // staging rounds (nl * lul <= 1024: checked by the launcher)
+      float4 v[NRD][8];
+      float hv[2];
+      int sdst[NRD];
+      unsigned sflag[NRD];  // bit 0: unit exists, bit 1: inside the picture, bits 8..: octet
+#pragma unroll
+      for (int i = 0; i < NRD; ++i) {
+        const int lu = tid + 512 * i;
+        const int j = min(lu / lul, p.nl - 1);
+        const int l2 = lu - j * lul;
+        const int o = l2 & 1, rr = (l2 >> 1) & 3, u = l2 >> 3;
+        const int R = u / nq, Q = u - R * nq;
+        const int r = 4 * R + rr;
+        const bool ex = lu < p.nl * lul && r < rows;
+        const int iy = gy0 - 1 + r, ix = gx0 + 4 * Q;
+        const bool ok = ex && iy >= 0 && iy < p.H && ix < p.W;
+        const float* src = p.dY[j] + ((long long)n * p.Cout) * p.cs + (ok ? iy * p.W + ix : 0);
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) {
+          const int ch = min(o * 8 + cc, p.Cout - 1);
+          v[i][cc] = *reinterpret_cast<const float4*>(src + (long long)ch * p.cs);
+        }
+        sdst[i] = j * LIMG + ((ex ? r : 0) * P + 1 + 4 * Q) * 32 + o * 16;
+        sflag[i] = (ex ? 1u : 0u) | (ok ? 2u : 0u) | ((unsigned)o << 8);
+      }
+      int hdst = 0;
+      unsigned hflag = 0;
+      {
+        const int hu = tid;
+        const int j = min(hu / hul, p.nl - 1);
+        const int h2 = hu - j * hul;
+        const int cp = h2 & 7, side = (h2 >> 3) & 1, r = h2 >> 4;
+        const bool ex = hu < p.nl * hul;
+        const int iy = gy0 - 1 + r, ix = side ? gx0 + p.tw : gx0 - 1;
+        const bool ok = ex && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        const float* src = p.dY[j] + ((long long)n * p.Cout) * p.cs + (ok ? iy * p.W + ix : 0);
+        hv[0] = src[(long long)min(2 * cp, p.Cout - 1) * p.cs];
+        hv[1] = src[(long long)min(2 * cp + 1, p.Cout - 1) * p.cs];
+        if (!ok || 2 * cp >= p.Cout) hv[0] = 0.f;
+        if (!ok || 2 * cp + 1 >= p.Cout) hv[1] = 0.f;
+        hdst = j * LIMG + ((ex ? r : 0) * P + (side ? p.tw + 1 : 0)) * 32 + cp * 4;
+        hflag = ex ? 1u : 0u;
+      }
+#pragma unroll
+      for (int i = 0; i < NRD; ++i) {
+        if (sflag[i] & 1u) {
+          const bool ok = (sflag[i] & 2u) != 0;
+          const int o = (int)(sflag[i] >> 8);
+#pragma unroll
+          for (int px = 0; px < 4; ++px) {
+            unsigned parts[4][NP];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float4 u0 = v[i][2 * k], u1 = v[i][2 * k + 1];
+              float x0 = px == 0 ? u0.x : px == 1 ? u0.y : px == 2 ? u0.z : u0.w;
+              float x1 = px == 0 ? u1.x : px == 1 ? u1.y : px == 2 ? u1.z : u1.w;
+              if (!ok || o * 8 + 2 * k >= p.Cout) x0 = 0.f;
+              if (!ok || o * 8 + 2 * k + 1 >= p.Cout) x1 = 0.f;
+              split2<DT, NP>(x0, x1, parts[k]);
+            }
+#pragma unroll
+            for (int pt = 0; pt < NP; ++pt)
+              *reinterpret_cast<uint4*>(smem + sdst[i] + pt * PLANE + px * 32) =
+                  make_uint4(parts[0][pt], parts[1][pt], parts[2][pt], parts[3][pt]);
+          }
+        }
+      }
+      if (hflag & 1u) {
+        unsigned parts[NP];
+        split2<DT, NP>(hv[0], hv[1], parts);
+#pragma unroll
+        for (int pt = 0; pt < NP; ++pt) *reinterpret_cast<unsigned*>(smem + hdst + pt * PLANE) = parts[pt];
+      }
+    }
+    __syncthreads();
+
+    // ---- per-wave loop over work items (no barriers) ----
+    const float* Sn = p.S + (long long)n * p.s_ns;
+    float* Gn = p.G + (long long)n * p.s_ns;
+    uint4 bf[5][NP];
+    bool bf_valid = false;
+#pragma unroll 1
+    for (int item = wave; item < 2 * ngroups; item += 8) {
+      const int g = item >> 1, half = item & 1;
+      int basem[MT], goff[MT];
+      unsigned vmask = 0;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int mt = half * MT + m;
+        {
+          const int q = min(mt * 16 + lp, npix - 1);
+          const int ty = q / p.tw, tx = q - ty * p.tw;
+          basem[m] = ((ty + 1) * P + tx + 1) * 32 + (lg & 1) * 16;
+        }
+        const int q = mt * 16 + lg * 4;
+        const int ty = q / p.tw, tx = q - ty * p.tw;
+        const int gy = gy0 + ty, gx = gx0 + tx;
+        const bool ok = q < npix && gy < p.H && gx < p.W;
+        vmask |= (ok ? 1u : 0u) << m;
+        goff[m] = ok ? gy * p.W + gx : 0;
+      }
+      const int c = g * 16 + lp;
+      const bool cv = c < p.C;
+      const int cc = cv ? c : p.C - 1;
+      const bool accum = c >= p.acc_lo && c < p.acc_hi;
+      const float* Sc = Sn + (long long)cc * p.cs;
+      float* Gc = Gn + (long long)cc * p.cs;
+      float4 sv[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) sv[m] = *reinterpret_cast<const float4*>(Sc + goff[m]);
+      const float mean = mtab[(g * 16 + lp) * 2], invstd = mtab[(g * 16 + lp) * 2 + 1];
+      f32x4 gsum[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) gsum[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (!bf_valid) {  // first (item, layer) of this wave in the tile: nothing was prefetched
+        const uint4* wp = p.wpk[0] + ((long long)g * 5 * NP) * 64 + lane;
+#pragma unroll
+        for (int s0 = 0; s0 < 5; ++s0)
+#pragma unroll
+          for (int pt = 0; pt < NP; ++pt) bf[s0][pt] = wp[(s0 * NP + pt) * 64];
+        bf_valid = true;
+      }
+#pragma unroll 1
+      for (int j = 0; j < p.nl; ++j) {
+        const unsigned char* img = smem + j * LIMG;
+        // weight fragments of the NEXT (item, layer): each k-step's registers are refilled as soon as the step is done,
+        // so the L2 latency of the 10 KB per (group, layer) hides behind the remaining steps and the epilogue
+        const bool last_layer = j + 1 == p.nl;
+        const int gn = last_layer ? ((item + 8) >> 1) : g;
+        const bool has_next = !last_layer || (item + 8 < 2 * ngroups);
+        const uint4* wpn = p.wpk[last_layer ? 0 : j + 1] + ((long long)(has_next ? gn : g) * 5 * NP) * 64 + lane;
+        const float4 cst = *reinterpret_cast<const float4*>(ctab + ((long long)j * Cpad + g * 16 + lp) * 4);
+        const float ea = cst.x, eb = cst.y, egam = cst.z;
+        f32x4 acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // keep the 25 x NP fragment addresses from being hoisted out of the layer loop as loop invariants (50+ VGPRs):
+        // the per-tile bases are re-materialised as opaque values in every layer iteration
+        int bm[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          bm[m] = basem[m];
+          asm volatile("" : "+v"(bm[m]));
+        }
+        constexpr int DEPTH = 4, RING = DEPTH + 1, STEPS = 5 * MT;
+        uint4 af[RING][NP];
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) {
+          const int s0 = i / MT, m0 = i - s0 * MT;
+#pragma unroll
+          for (int pt = 0; pt < NP; ++pt)
+            af[i % RING][pt] = *reinterpret_cast<const uint4*>(img + pt * PLANE + bm[m0] + toff[s0]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < STEPS; ++i) {
+          const int s = i / MT, m = i - s * MT;
+          if (i + DEPTH < STEPS) {
+            const int s1 = (i + DEPTH) / MT, m1 = (i + DEPTH) - s1 * MT;
+#pragma unroll
+            for (int pt = 0; pt < NP; ++pt)
+              af[(i + DEPTH) % RING][pt] = *reinterpret_cast<const uint4*>(img + pt * PLANE + bm[m1] + toff[s1]);
+          }
+          acc[m] = mfma_split<DT, NP>(af[i % RING], bf[s], acc[m]);
+          if (m == MT - 1) {
+#pragma unroll
+            for (int pt = 0; pt < NP; ++pt) bf[s][pt] = wpn[(s * NP + pt) * 64];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // epilogue of layer j: ReLU mask of the layer's BatchNorm output, BN-backward sums, gamma-weighted sum
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const bool ok = cv && ((vmask >> m) & 1u);
+          const float xs[4] = {sv[m].x, sv[m].y, sv[m].z, sv[m].w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float yv = fmaf(ea, xs[r], eb);
+            const float gz = (ok && yv > 0.f) ? acc[m][r] : 0.f;
+            const float xh = (xs[r] - mean) * invstd;
+            s1 += gz;
+            s2 += gz * xh;
+            gsum[m][r] = fmaf(egam, gz, gsum[m][r]);
+          }
+        }
+        s1 = group4_sum(s1);
+        s2 = group4_sum(s2);
+        if (lg == 0) {  // (half, layer, channel) slots are owned by exactly one wave per tile: plain read-modify-write
+          float* st = stats + (((long long)half * p.nl + j) * Cpad + g * 16 + lp) * 2;
+          st[0] += s1;
+          st[1] += s2;
+        }
+      }
+      // write G once (the activations are dead by now: their registers take the old gradient where it accumulates)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        sv[m] = accum ? *reinterpret_cast<const float4*>(Gc + goff[m]) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        if (cv && ((vmask >> m) & 1u))
+          *reinterpret_cast<float4*>(Gc + goff[m]) = make_float4(gsum[m][0] + sv[m].x, gsum[m][1] + sv[m].y,
+                                                                 gsum[m][2] + sv[m].z, gsum[m][3] + sv[m].w);
+      }
+    }
+  }
+  __syncthreads();
+  if (p.stat_partial != nullptr) {  // rows: [block][half]
+    float* dst = p.stat_partial + (long long)blockIdx.x * 2 * p.nl * Cpad * 2;
+    for (int i = tid; i < 2 * p.nl * Cpad * 2; i += 512) dst[i] = stats[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void d3_pull_finalize_k(const D3PullFin f) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= f.C) return;
+  float a1 = 0.f, a2 = 0.f;
+  for (int j = 0; j < f.nl; ++j) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = lane; r < f.rows; r += 64) {
+      const float* q = f.partial + (((long long)r * f.nl + j) * f.Cpad + c) * 2;
+      s1 += (double)q[0];
+      s2 += (double)q[1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s1 += __shfl_xor(s1, o, 64);
+      s2 += __shfl_xor(s2, o, 64);
+    }
+    if (lane == 0) {
+      f.dbeta[j][c] = (float)s1;
+      f.dgamma[j][c] = (float)s2;
+      const float g = f.gamma[j][c];
+      a1 += g * (float)s1;
+      a2 += g * (float)s2;
+    }
+  }
+  if (lane == 0) {
+    f.S1[c] += a1;
+    f.S2[c] += a2;
+  }
+}
+
+int d3_pull_finalize(const D3PullFin& f, hipStream_t s) {
+  hipLaunchKernelGGL(d3_pull_finalize_k, dim3((unsigned)((f.C + 3) / 4)), dim3(256), 0, s, f);
+  return (int)hipGetLastError();
+}
+
+static size_t d3_pull_lds(const D3Pull& p, int np) {
+  const int P = p.tw + 3, rows = p.th + 2;
+  const int Cpad = ((p.C + 15) / 16) * 16;
+  return (size_t)p.nl * np * rows * P * 32 + (size_t)2 * p.nl * Cpad * 2 * 4 + (size_t)p.nl * Cpad * 16 + (size_t)Cpad * 8;
+}
+
+bool d3_pull_supported(const D3Pull& p, int np) {
+  if (p.nl < 1 || p.nl > D3_LMAX || p.Cout < 1 || p.Cout > 16 || p.C < 1) return false;
+  if (p.nl * 8 * ((p.th + 2 + 3) / 4) * (p.tw / 4) > 1024 || p.nl * (p.th + 2) * 16 > 512) return false;  // staging rounds
+  if (p.th * p.tw != 160 || d3_pull_lds(p, np) > 160 * 1024) return false;
+  if ((p.W & 3) || (p.cs & 3) || (p.s_ns & 3)) return false;
+  if (!(p.W % 80 == 0 || p.W == 40)) return false;
+  if ((reinterpret_cast<uintptr_t>(p.S) & 15) || (reinterpret_cast<uintptr_t>(p.G) & 15)) return false;
+  for (int j = 0; j < p.nl; ++j)
+    if (reinterpret_cast<uintptr_t>(p.dY[j]) & 15) return false;
+  return true;
+}
+
+void d3_pull_pick_tile(int H, int W, int* th, int* tw) {
+  (void)H;
+  if (W % 80 == 0) {
+    *tw = 80;
+    *th = 2;
+  } else {
+    *tw = 40;
+    *th = 4;
+  }
+}
+
+int d3_pull_blocks(const D3Pull& p) {
+  const long long total = (long long)p.tiles_x * p.tiles_y * p.N;
+  return (int)std::min<long long>(total, 256);
+}
+
+template <int NP, int DT>
+static int d3_pull_launch_t(const D3Pull& p, hipStream_t s) {
+  const size_t lds = d3_pull_lds(p, NP);
+  if (lds > 160 * 1024) return -4;
+  auto kern = d3_pull_k<NP, DT>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    (void)hipGetLastError();
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)d3_pull_blocks(p)), dim3(512), lds, s, p);
+  return (int)hipGetLastError();
+}
+
+int d3_pull_launch(const D3Pull& p, int np, int dt, hipStream_t s) {
+  if (!d3_pull_supported(p, np)) return -4;
+  if (dt == D3_BF16) {
+    if (np == 1) return d3_pull_launch_t<1, D3_BF16>(p, s);
+    if (np == 2) return d3_pull_launch_t<2, D3_BF16>(p, s);
+    return d3_pull_launch_t<3, D3_BF16>(p, s);
+  }
+  if (np == 1) return d3_pull_launch_t<1, D3_F16>(p, s);
+  return d3_pull_launch_t<2, D3_F16>(p, s);
+}
+
 }  // namespace rln

@@ -168,6 +168,7 @@ struct rln_ctx {
   D3PackDesc* d3_desc_b_dev = nullptr;
   uint4* d3_packed = nullptr;
   int d3_units_f = 0, d3_units_b = 0;
+  std::vector<float*> dyblk;  // one finalised-output-gradient buffer per layer of a dense block (pull-form backward)
 };
 
 namespace {
@@ -491,6 +492,7 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
       }
       if (with_bwd) {
         stat_max = std::max(stat_max, blocks * o.cin * 2);
+        if (c->d3_bwd_np > 0) stat_max = std::max(stat_max, (size_t)512 * D3_LMAX * (((size_t)o.cin + 15) / 16 * 16) * 2);
         dy_max = std::max(dy_max, (size_t)n * o.cout * Hd * Wd);
         bp_max = std::max(bp_max, (size_t)grad_finalize_rows(n, Hd, Wd) * o.cout);
         int wth, wtw, ipc;
@@ -501,6 +503,11 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
                                         wgrad_chunks(items, (o.cout + 15) / 16, (o.cin + 31) / 32, &ipc, 1536),
                                         wgrad_chunks(items, (o.cout + 15) / 16, (o.cin + 15) / 16, &ipc, 2048)});
         wp_max = std::max(wp_max, (size_t)nch * o.cout * o.cin * 9);
+        if (c->d3_bwd_np > 0 && o.type == OP_DENSE) {
+          D3Wgrad g;
+          d3_wgrad_plan(Hd, Wd, n, o.cin, &g);
+          wp_max = std::max(wp_max, (size_t)g.nranges * o.cout * o.cin * 9);
+        }
       }
     } else if (o.type == OP_TD) {
       const int Hs = hs[o.src_level], Ws = ws[o.src_level];
@@ -586,6 +593,23 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
       dbh.push_back(d);
     }
   }
+  // pull-form data gradient: the dY of every layer of a block stays alive until the block's input channels are done
+  int max_block_layers = 0;
+  size_t dy_dense_max = 0;
+  if (c->d3_bwd_np > 0 && with_bwd) {
+    int run = 0;
+    for (size_t k = 0; k < c->ops.size(); ++k) {
+      const Op& o = c->ops[k];
+      const bool cont = o.type == OP_DENSE && k > 0 && c->ops[k - 1].type == OP_DENSE &&
+                        c->ops[k - 1].src_level == o.src_level && c->ops[k - 1].in_off == o.in_off;
+      run = o.type == OP_DENSE ? (cont ? run + 1 : 1) : 0;
+      max_block_layers = std::max(max_block_layers, run);
+      if (o.type == OP_DENSE)
+        dy_dense_max = std::max(dy_dense_max, (size_t)n * o.cout * hs[o.dst_level] * ws[o.dst_level]);
+    }
+  }
+  std::vector<float*> dyblk(max_block_layers, nullptr);
+  for (int i = 0; i < max_block_layers; ++i) dyblk[i] = cv.take<float>(dy_dense_max);
   uint4* d3_packed = cv.take<uint4>((size_t)pk_total);
   D3PackDesc* d3_df = cv.take<D3PackDesc>(dfh.size());
   D3PackDesc* d3_db = cv.take<D3PackDesc>(dbh.size());
@@ -617,6 +641,7 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
     c->wpartial = wpartial;
     c->bpartial = bpartial;
     c->glin = glin;
+    c->dyblk = dyblk;
     c->d3_desc_f = dfh;
     c->d3_desc_b = dbh;
     c->d3_wf_off = wf_off;
@@ -887,7 +912,7 @@ HeadParams head_params(rln_ctx* c) {
 // ---------------------------------------------------------------------------------------------
 
 int finalize_grad_range(rln_ctx* c, int level, int ch_off, int C, const float* nscale, long long* rows,
-                        hipStream_t s) {
+                        hipStream_t s, float* dst = nullptr) {
   const Level& lv = c->levels[level];
   GradFinParams g;
   memset(&g, 0, sizeof(g));
@@ -905,7 +930,7 @@ int finalize_grad_range(rln_ctx* c, int level, int ch_off, int C, const float* n
   g.S2 = c->S2 + so;
   g.invM = (float)(1.0 / ((double)c->N * plane));
   g.nscale = nscale;
-  g.dst = c->dY;
+  g.dst = dst ? dst : c->dY;
   g.bias_partial = c->bpartial;
   g.Hd = lv.H;
   g.Wd = lv.W;
@@ -1274,6 +1299,202 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Backward of a whole DenseBlock (ops k0..k1, same level, same input offset) with the pull-form data gradient:
+//   for j = L-1 .. 0:  finalise dY_j (kept), weight/bias gradient of layer j, and the layer's data gradient restricted
+//                      to the block's NEW channels [C0, C0 + growth*j) (they must be complete before layer j-1 is
+//                      finalised: read-modify-write on at most 64 channels);
+//   then ONE pass over the block's input channels [0, C0) that pulls the contributions of all layers (d3_pull_k).
+// Returns kNotCovered when the block is not covered (caller falls back to the per-layer path), 0 on success.
+// ---------------------------------------------------------------------------------------------
+constexpr int kNotCovered = 1 << 20;
+int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
+  const int L = k1 - k0 + 1;
+  const Op& first = c->ops[(size_t)k0];
+  const Level& lv = c->levels[first.src_level];
+  const size_t plane = (size_t)lv.H * lv.W;
+  const int N = c->N;
+  const int C0 = first.cin;
+  if (c->d3_bwd_np <= 0 || L > (int)c->dyblk.size()) return kNotCovered;
+  D3Pull q;
+  memset(&q, 0, sizeof(q));
+  q.Cout = first.cout;
+  q.mean = c->mean + lv.stat_off + first.in_off;
+  q.invstd = c->invstd + lv.stat_off + first.in_off;
+  q.S = lv.S + (size_t)first.in_off * plane;
+  q.G = lv.G + (size_t)first.in_off * plane;
+  q.s_ns = (long long)lv.C * plane;
+  q.cs = (int)plane;
+  q.C = C0;
+  q.H = lv.H;
+  q.W = lv.W;
+  q.N = N;
+  q.nl = std::min(L, D3_LMAX);
+  for (int i = 0; i < q.nl; ++i) q.dY[i] = c->dyblk[(size_t)i];
+  d3_pull_pick_tile(q.H, q.W, &q.th, &q.tw);
+  q.tiles_y = (q.H + q.th - 1) / q.th;
+  q.tiles_x = (q.W + q.tw - 1) / q.tw;
+  if (!d3_pull_supported(q, c->d3_bwd_np) || first.cout > 16) return kNotCovered;
+  for (int j = 0; j < L; ++j)
+    if (c->d3_wb_off[(size_t)k0 + j] < 0) return kNotCovered;
+
+  for (int j = L - 1; j >= 0; --j) {
+    const Op& o = c->ops[(size_t)k0 + j];
+    long long rows = 0;
+    const float* nscale = (o.drop_ch >= 0) ? (c->masks + (size_t)N * o.drop_ch) : nullptr;
+    float* dYj = c->dyblk[(size_t)j];
+    RLN_TRY(finalize_grad_range(c, o.dst_level, o.out_off, o.cout, nscale, &rows, s, dYj));
+    RLN_TRY(reduce_rows(c->bpartial, rows, o.cout, c->grads + o.conv.b, s));
+    {  // weight gradient of layer j
+      WgradParams w;
+      memset(&w, 0, sizeof(w));
+      w.u = dYj;
+      w.u_ns = (long long)o.cout * plane;
+      w.u_cs = (int)plane;
+      w.Uc = o.cout;
+      w.GH = lv.H;
+      w.GW = lv.W;
+      w.Hv = lv.H;
+      w.Wv = lv.W;
+      w.Vc = o.cin;
+      w.v_cs = (int)plane;
+      w.wsize = (long long)o.cout * o.cin * 9;
+      w.m_stride = (long long)o.cin * 9;
+      w.n_stride = 9;
+      w.v = lv.S + (size_t)o.in_off * plane;
+      w.v_ns = (long long)lv.C * plane;
+      w.pa = c->ab + o.bn.ab;
+      w.pb = c->ab + c->n_ab + o.bn.ab;
+      D3Wgrad g;
+      memset(&g, 0, sizeof(g));
+      g.S = w.v;
+      g.ns = w.v_ns;
+      g.cs = (int)plane;
+      g.H = lv.H;
+      g.W = lv.W;
+      g.Cin = o.cin;
+      g.pa = w.pa;
+      g.pb = w.pb;
+      g.dY = dYj;
+      g.Cout = o.cout;
+      g.N = N;
+      g.partial = c->wpartial;
+      if (d3_wgrad_supported(g)) {  // transposed-read 16-bit MFMA kernel
+        d3_wgrad_plan(lv.H, lv.W, N, o.cin, &g);
+        {
+          const double wflops = 2.0 * o.cout * o.cin * 9.0 * plane * N;
+          const double wbytes = 4.0 * N * ((double)o.cout + o.cin) * plane;
+          ProfScope ps(c, PC_DENSE_WGRAD, wflops, wbytes, s);
+          RLN_TRY(d3_wgrad_launch(g, c->d3_bwd_np, c->d3_bwd_dt, s));
+        }
+        ProfScope ps2(c, PC_REDUCE, 0, 4.0 * (g.nranges + 1) * w.wsize, s);
+        RLN_TRY(reduce_rows(c->wpartial, g.nranges, w.wsize, c->grads + o.conv.w, s));
+      } else {
+        RLN_TRY(run_wgrad(c, WG_DENSE3, w, o.cout, o.cin, o.conv.w, s));
+      }
+    }
+    const int Jn = o.cin - C0;  // new channels this layer consumes
+    if (Jn > 0) {
+      IgemmParams p;
+      memset(&p, 0, sizeof(p));
+      p.in = dYj;
+      p.in_ns = (long long)o.cout * plane;
+      p.in_cs = (int)plane;
+      p.Hin = lv.H;
+      p.Win = lv.W;
+      p.K = o.cout;
+      p.w = c->params + o.conv.w + (long long)C0 * 9;  // W[o][c][tap], c offset C0
+      p.w_ks = (long long)o.cin * 9;
+      p.w_js = 9;
+      p.tapmode = TM_FLIP;
+      p.J = Jn;
+      p.GH = lv.H;
+      p.GW = lv.W;
+      p.ncls = 1;
+      p.out = lv.G + (size_t)(o.in_off + C0) * plane;
+      p.out_ns = (long long)lv.C * plane;
+      p.out_cs = (int)plane;
+      p.Hout = lv.H;
+      p.Wout = lv.W;
+      p.S = lv.S + (size_t)(o.in_off + C0) * plane;
+      p.s_ns = p.out_ns;
+      const int64_t so = lv.stat_off + o.in_off + C0;
+      p.ea = c->ab + o.bn.ab + C0;
+      p.eb = c->ab + c->n_ab + o.bn.ab + C0;
+      p.emean = c->mean + so;
+      p.einvstd = c->invstd + so;
+      p.egamma = c->params + o.bn.gamma + C0;
+      p.acc_lo = std::max(0, o.acc_lo - C0);
+      p.acc_hi = std::max(0, o.acc_hi - C0);
+      p.stat_partial = c->stat_partial;
+      const int tile = igemm_pick_tile(p.GH, p.GW);
+      int th, tw;
+      igemm_tile_dims(IG_DGRAD3, tile, &th, &tw);
+      p.tiles_y = (p.GH + th - 1) / th;
+      p.tiles_x = (p.GW + tw - 1) / tw;
+      p.out_vec = ((lv.W % 4) == 0 && aligned16(p.out) && aligned16(p.S)) ? 1 : 0;
+      {
+        const double flops = 2.0 * Jn * o.cout * 9.0 * plane * N;
+        const double bytes = 4.0 * N * plane * ((double)o.cout + 2.0 * Jn + (double)(p.acc_hi - p.acc_lo));
+        ProfScope ps(c, PC_DENSE_DGRAD, flops, bytes, s);
+        if (o.cout <= 16) {
+          RLN_TRY(dgrad_loop_launch(tile, p, N, s));
+        } else {
+          RLN_TRY(igemm_launch(IG_DGRAD3, tile, p, N, s));
+        }
+      }
+      ProfScope psb(c, PC_BN, 0, 0, s);
+      RLN_TRY(bn_bwd_finalize(c->stat_partial, igemm_stat_blocks(p, N), Jn, c->params + o.bn.gamma + C0,
+                              c->grads + o.bn.gamma + C0, c->grads + o.bn.beta + C0, c->S1 + so, c->S2 + so, s));
+    }
+  }
+  // input channels [0, C0): all layers at once (passes of at most D3_LMAX layers)
+  const Op& last = c->ops[(size_t)k1];
+  for (int j0 = L - 1, pass = 0; j0 >= 0; j0 -= D3_LMAX, ++pass) {
+    const int nl = std::min(D3_LMAX, j0 + 1);
+    q.nl = nl;
+    D3PullFin f;
+    memset(&f, 0, sizeof(f));
+    for (int i = 0; i < nl; ++i) {
+      const int j = j0 - i;
+      const Op& o = c->ops[(size_t)k0 + j];
+      q.dY[i] = c->dyblk[(size_t)j];
+      q.wpk[i] = c->d3_packed + c->d3_wb_off[(size_t)k0 + j];
+      q.ea[i] = c->ab + o.bn.ab;
+      q.eb[i] = c->ab + c->n_ab + o.bn.ab;
+      q.egamma[i] = c->params + o.bn.gamma;
+      f.gamma[i] = c->params + o.bn.gamma;
+      f.dgamma[i] = c->grads + o.bn.gamma;
+      f.dbeta[i] = c->grads + o.bn.beta;
+    }
+    if (pass == 0) {  // channels that held gradient before the block's backward started
+      q.acc_lo = std::min(last.acc_lo, C0);
+      q.acc_hi = std::min(last.acc_hi, C0);
+    } else {
+      q.acc_lo = 0;
+      q.acc_hi = C0;
+    }
+    q.stat_partial = c->stat_partial;
+    {
+      double flops = 0.0;
+      for (int i = 0; i < nl; ++i) flops += 2.0 * C0 * first.cout * 9.0 * plane * N;
+      const double bytes = 4.0 * N * plane * ((double)nl * first.cout + 2.0 * C0 + (double)(q.acc_hi - q.acc_lo));
+      ProfScope ps(c, PC_DENSE_DGRAD, flops, bytes, s);
+      RLN_TRY(d3_pull_launch(q, c->d3_bwd_np, c->d3_bwd_dt, s));
+    }
+    f.nl = nl;
+    f.C = C0;
+    f.Cpad = ((C0 + 15) / 16) * 16;
+    f.rows = 2 * d3_pull_blocks(q);
+    f.partial = c->stat_partial;
+    f.S1 = c->S1 + lv.stat_off + first.in_off;
+    f.S2 = c->S2 + lv.stat_off + first.in_off;
+    ProfScope psb(c, PC_BN, 0, 0, s);
+    RLN_TRY(d3_pull_finalize(f, s));
+  }
+  return 0;
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -1538,8 +1759,22 @@ int rln_backward(rln_ctx* c, float loss_scale, int seg_begin, int seg_end, void*
     }
   }
   for (int seg = std::max(seg_begin, 1); seg < seg_end; ++seg) {
-    for (int k = (int)c->ops.size() - 1; k >= 0; --k)
-      if (c->ops[k].seg == seg) RLN_TRY(bwd_op(c, (size_t)k, s));
+    for (int k = (int)c->ops.size() - 1; k >= 0; --k) {
+      if (c->ops[k].seg != seg) continue;
+      if (c->ops[k].type == OP_DENSE && c->d3_bwd_np > 0 && !c->use_side) {  // whole dense block at once (pull form)
+        int k0 = k;
+        while (k0 > 0 && c->ops[k0 - 1].type == OP_DENSE && c->ops[k0 - 1].src_level == c->ops[k].src_level &&
+               c->ops[k0 - 1].in_off == c->ops[k].in_off)
+          --k0;
+        const int r = bwd_dense_block(c, k0, k, s);
+        if (r != 0 && r != kNotCovered) return r;
+        if (r == 0) {
+          k = k0;  // the loop decrement moves on to the op in front of the block
+          continue;
+        }
+      }
+      RLN_TRY(bwd_op(c, (size_t)k, s));
+    }
   }
   // join: everything this call produced (incl. side-stream weight gradients) is ordered before later work on `s`
   for (int b = 0; b < 2; ++b) {

@@ -5,6 +5,7 @@ streams only; every arithmetic op of the path runs in librln.so.
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -41,6 +42,25 @@ class TensorMeta:
         return n
 
 
+def parse_dense_arith(text):
+    """'f16x2,bf16x2' -> (2, 'f16', 2, 'bf16'); 'fp32' = exact fp32 MFMA kernels (0 parts)."""
+    def one(a):
+        a = a.strip()
+        if a in ("", "fp32"):
+            return 0, "bf16"
+        t, n = a.split("x")
+        return int(n), t
+    f, _, b = text.partition(",")
+    fp, ft = one(f)
+    bp, bt = one(b)
+    return fp, ft, bp, bt
+
+
+# Arithmetic of the dense 3x3 layers used by every new Engine unless the caller passes dense_arith= (include/rln.h:
+# rln_set_dense_arith).  RLN_DENSE_ARITH overrides it for experiments, e.g. "fp32,fp32" or "f16x2,bf16x2".
+DEFAULT_DENSE_ARITH = parse_dense_arith(os.environ["RLN_DENSE_ARITH"]) if os.environ.get("RLN_DENSE_ARITH") else None
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -56,7 +76,7 @@ class Engine:
     tensors aliasing them under the reference's state_dict names.
     """
 
-    def __init__(self, spec: NetSpec, device="cpu"):
+    def __init__(self, spec: NetSpec, device="cpu", dense_arith=None):
         self.spec = spec
         self.L = _lib.lib()
         cfg = _lib.make_config(spec.in_channels, spec.down_blocks, spec.up_blocks, spec.bottleneck_layers,
@@ -95,7 +115,11 @@ class Engine:
         self._ws_key = None
         self._keep = []
         self.step_seed = 0
+        self.dense_arith = (0, "bf16", 0, "bf16")
         self.allocate(device)
+        arith = DEFAULT_DENSE_ARITH if dense_arith is None else dense_arith
+        if arith is not None:
+            self.set_dense_arith(*arith)
 
     def __del__(self):
         try:
