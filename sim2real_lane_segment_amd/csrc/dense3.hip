@@ -233,21 +233,21 @@ __global__ __launch_bounds__(768, 3) void d3_fwd_k(const D3Fwd p) {
 
   if (producer) {
     // =========================== producer waves ===========================
-    const int pgroup = (wave - 4) >> 2;  // 0: chunks c_begin+1, +3, ...   1: chunks c_begin, +2, ...
-    const int ptid = tid & 255;
+    // All 8 producer waves work on EVERY chunk: thread -> one staging unit (8 channels x 4 pixels); threads below
+    // rows*16 additionally fetch one halo-column channel pair, every thread two weight-fragment entries.  Every thread
+    // issues the same 12 loads per chunk (clamped where it has nothing to fetch): no branches around loads, exact wait
+    // counters.  Two register sets hold the chunks of even / odd iteration: a chunk's loads stay in flight for two
+    // iterations (~130 KB per CU outstanding).
+    const int ptid = tid - 256;
     const int nq = p.tw >> 2;
-    int s_off[NR][8], s_lds[NR];
-    bool s_ok[NR];
-    int s_o[NR];
-    // 8-lane group = 2 channel octets x RG rows x (4/RG) pixel quads (RG = 4: conflict-free 16-byte LDS writes;
-    // RG = 2: 2-way, fewer idle lanes when th+2 is not a multiple of 4)
-    const int rgs = p.rg == 2 ? 1 : 2;        // log2(RG)
+    const int rgs = p.rg == 2 ? 1 : 2;        // log2(rows per 8-lane group)
     const int qpg = 4 >> rgs;                 // quads per group
     const int nqg = (nq + qpg - 1) / qpg;     // groups per row band
     const int nrg = (rows + p.rg - 1) >> rgs; // row bands
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      const int lu = ptid + 256 * i;
+    int s_off[8], s_lds, s_o;
+    bool s_ok;
+    {
+      const int lu = ptid;
       const int o = lu & 1, rr = (lu >> 1) & (p.rg - 1), qq = (lu >> (1 + rgs)) & (qpg - 1), u = lu >> 3;
       const int R = u / nqg, Q = (u - R * nqg) * qpg + qq;
       const int r = (R << rgs) + rr;
@@ -256,12 +256,12 @@ __global__ __launch_bounds__(768, 3) void d3_fwd_k(const D3Fwd p) {
 #ifdef RLN_DIAG
       if ((p.dbg & 16) && (r == 0 || r == rows - 1)) ok = false;  // timing ablation: no halo rows
 #endif
-      s_ok[i] = ok;
+      s_ok = ok;
       const int goff = ok ? iy * p.W + ix : 0;
 #pragma unroll
-      for (int cc = 0; cc < 8; ++cc) s_off[i][cc] = (o * 8 + cc) * p.cs + goff;  // relative to the chunk's first plane
-      s_lds[i] = ((ok ? r : 0) * P + 1 + 4 * (ok ? Q : 0)) * 32 + o * 16;
-      s_o[i] = o;
+      for (int cc = 0; cc < 8; ++cc) s_off[cc] = (o * 8 + cc) * p.cs + goff;  // relative to the chunk's first plane
+      s_lds = ((ok ? r : 0) * P + 1 + 4 * (ok ? Q : 0)) * 32 + o * 16;
+      s_o = o;
     }
     // halo columns: unit = (row, side, channel pair)
     const int h_cp = ptid & 7, h_side = (ptid >> 3) & 1, h_r = ptid >> 4;
@@ -269,75 +269,60 @@ __global__ __launch_bounds__(768, 3) void d3_fwd_k(const D3Fwd p) {
     const bool h_ok = (h_r < rows) && (h_iy >= 0) && (h_iy < p.H) && (h_ix >= 0) && (h_ix < p.W);
     const int h_goff = (h_ok ? h_iy * p.W + h_ix : 0) + 2 * h_cp * p.cs;
     const int h_lds = ((h_ok ? h_r : 0) * P + (h_side ? p.tw + 1 : 0)) * 32 + h_cp * 4;
-    constexpr int NB = (5 * NP * 64 + 255) / 256;  // weight-fragment entries per producer thread
+    constexpr int NBE = 5 * NP * 64;             // weight-fragment entries per chunk
+    constexpr int NB = (NBE + 511) / 512;        // per producer thread
 
-    float4 sreg[NR][8];
-    float hreg[2];
-    uint4 breg[NB];
+    struct Stage {
+      float4 s[8];
+      float h[2];
+      uint4 b[NB];
+    };
+    Stage RA, RB;
     // the tail chunk of a Cin that is no multiple of 16 starts at Cin-16 (see d3_pack_k): no clamping needed
     auto chunk_base = [&](int chunk) __attribute__((always_inline)) { return min(chunk * 16, max(p.Cin - 16, 0)); };
-    // issue_part / commit_part: part 0 = weight fragments + halo columns, part 1+i = staging round i
-    auto issue_part = [&](int chunk, auto PART) __attribute__((always_inline)) {
-      constexpr int part = decltype(PART)::value;
+    auto issue = [&](int chunk, Stage& R) __attribute__((always_inline)) {
 #ifdef RLN_DIAG
       if (p.dbg & 1) return;
 #endif
       const float* base = Sn + (long long)chunk_base(chunk) * p.cs;  // wave-uniform
-      if constexpr (part == 0) {
-        const uint4* wp = p.wpk + (long long)chunk * 5 * NP * 64;
+      const uint4* wp = p.wpk + (long long)chunk * NBE;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) breg[i] = wp[min(ptid + 256 * i, 5 * NP * 64 - 1)];
-        hreg[0] = base[h_goff];
-        hreg[1] = base[h_goff + p.cs];
-      } else {
-        constexpr int i = part - 1;
+      for (int i = 0; i < NB; ++i) R.b[i] = wp[min(ptid + 512 * i, NBE - 1)];
 #pragma unroll
-        for (int cc = 0; cc < 8; ++cc) sreg[i][cc] = *reinterpret_cast<const float4*>(base + s_off[i][cc]);
-      }
+      for (int cc = 0; cc < 8; ++cc) R.s[cc] = *reinterpret_cast<const float4*>(base + s_off[cc]);
+      R.h[0] = base[h_goff];
+      R.h[1] = base[h_goff + p.cs];
     };
-    using P0 = std::integral_constant<int, 0>;
-    using P1 = std::integral_constant<int, 1>;
-    using P2 = std::integral_constant<int, 2>;
-    auto issue = [&](int chunk) __attribute__((always_inline)) {
-      issue_part(chunk, P0{});
-      issue_part(chunk, P1{});
-      if constexpr (NR > 1) issue_part(chunk, P2{});
-    };
-    auto commit_part = [&](int chunk, unsigned char* buf, auto PART) __attribute__((always_inline)) {
-      constexpr int part = decltype(PART)::value;
+    auto commit = [&](int chunk, unsigned char* buf, const Stage& R) __attribute__((always_inline)) {
 #ifdef RLN_DIAG
       if (p.dbg & 2) return;
 #endif
       const int cb = chunk_base(chunk);
-      if constexpr (part == 0) {
-        uint4* btile = reinterpret_cast<uint4*>(buf + NP * PLANE);
+      uint4* btile = reinterpret_cast<uint4*>(buf + NP * PLANE);
 #pragma unroll
-        for (int i = 0; i < NB; ++i)
-          if (ptid + 256 * i < 5 * NP * 64) btile[ptid + 256 * i] = breg[i];
-        if (h_ok) {
-          const int c0 = cb + 2 * h_cp;
-          unsigned parts[NP];
-          split2<DT, NP>(fmaxf(fmaf(abtab[c0], hreg[0], abtab[Cpad + c0]), 0.f),
-                         fmaxf(fmaf(abtab[c0 + 1], hreg[1], abtab[Cpad + c0 + 1]), 0.f), parts);
+      for (int i = 0; i < NB; ++i)
+        if (ptid + 512 * i < NBE) btile[ptid + 512 * i] = R.b[i];
+      if (h_ok) {
+        const int c0 = cb + 2 * h_cp;
+        unsigned parts[NP];
+        split2<DT, NP>(fmaxf(fmaf(abtab[c0], R.h[0], abtab[Cpad + c0]), 0.f),
+                       fmaxf(fmaf(abtab[c0 + 1], R.h[1], abtab[Cpad + c0 + 1]), 0.f), parts);
 #pragma unroll
-          for (int pt = 0; pt < NP; ++pt) *reinterpret_cast<unsigned*>(buf + pt * PLANE + h_lds) = parts[pt];
-        }
-        return;
+        for (int pt = 0; pt < NP; ++pt) *reinterpret_cast<unsigned*>(buf + pt * PLANE + h_lds) = parts[pt];
       }
-      constexpr int i = part > 0 ? part - 1 : 0;
-      const float* ab = abtab + cb + s_o[i] * 8;
-      const float4 a0 = *reinterpret_cast<const float4*>(ab), a1 = *reinterpret_cast<const float4*>(ab + 4);
-      const float4 b0 = *reinterpret_cast<const float4*>(ab + Cpad);
-      const float4 b1 = *reinterpret_cast<const float4*>(ab + Cpad + 4);
-      const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-      const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-      if (s_ok[i]) {
+      if (s_ok) {
+        const float* ab = abtab + cb + s_o * 8;
+        const float4 a0 = *reinterpret_cast<const float4*>(ab), a1 = *reinterpret_cast<const float4*>(ab + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(ab + Cpad);
+        const float4 b1 = *reinterpret_cast<const float4*>(ab + Cpad + 4);
+        const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
           unsigned parts[4][NP];
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const float4 u0 = sreg[i][2 * k], u1 = sreg[i][2 * k + 1];
+            const float4 u0 = R.s[2 * k], u1 = R.s[2 * k + 1];
             const float x0 = px == 0 ? u0.x : px == 1 ? u0.y : px == 2 ? u0.z : u0.w;
             const float x1 = px == 0 ? u1.x : px == 1 ? u1.y : px == 2 ? u1.z : u1.w;
             split2<DT, NP>(fmaxf(fmaf(av[2 * k], x0, bv[2 * k]), 0.f),
@@ -345,67 +330,39 @@ __global__ __launch_bounds__(768, 3) void d3_fwd_k(const D3Fwd p) {
           }
 #pragma unroll
           for (int pt = 0; pt < NP; ++pt)
-            *reinterpret_cast<uint4*>(buf + pt * PLANE + s_lds[i] + px * 32) =
+            *reinterpret_cast<uint4*>(buf + pt * PLANE + s_lds + px * 32) =
                 make_uint4(parts[0][pt], parts[1][pt], parts[2][pt], parts[3][pt]);
         }
       }
     };
-    auto commit = [&](int chunk, unsigned char* buf) __attribute__((always_inline)) {
-      commit_part(chunk, buf, P0{});
-      commit_part(chunk, buf, P1{});
-      if constexpr (NR > 1) commit_part(chunk, buf, P2{});
-    };
-    // steady state: every part's registers are refilled (chunk `next`) right after they are consumed (chunk `cur`)
-    auto commit_issue = [&](int cur, unsigned char* buf, int next) __attribute__((always_inline)) {
-      commit_part(cur, buf, P0{});
-      issue_part(next, P0{});
-      commit_part(cur, buf, P1{});
-      issue_part(next, P1{});
-      if constexpr (NR > 1) {
-        commit_part(cur, buf, P2{});
-        issue_part(next, P2{});
-      }
-    };
-
-    // Iteration i (consumers multiply chunk c_begin+i, one barrier at its end): the group with (i & 1) == pgroup
-    // commits chunk c_begin+i+1 and re-issues its registers for chunk c_begin+i+3; the other group only waits.
-    // Group 1 also stages the first chunk before iteration 0.
+    // chunk c_begin+i lives in set i & 1.  Iteration i (consumers multiply chunk i): commit chunk i+1 into the other
+    // LDS buffer, refill its register set with chunk i+3.
     const int nck = c_end - c_begin;
-    if (pgroup == 1) {
-      if (nck > 0) issue(c_begin);     // in flight while the padding cells are zeroed
-      lds_setup();
+    auto bufof = [&](int i) __attribute__((always_inline)) { return smem + ((c_begin + i) & 1) * IMG; };
+    if (nck > 0) issue(c_begin, RA);
+    if (nck > 1) issue(c_begin + 1, RB);
+    lds_setup();
+    __syncthreads();
+    if (nck > 0) commit(c_begin, bufof(0), RA);
+    if (nck > 2) issue(c_begin + 2, RA);
+    __syncthreads();  // start of iteration 0
+    int i = 0;
+    for (; i + 4 < nck; i += 2) {  // steady state, two iterations per trip, no branches around the loads
+      commit(c_begin + i + 1, bufof(i + 1), RB);
+      issue(c_begin + i + 3, RB);
       __syncthreads();
-      if (nck > 0) {
-        commit(c_begin, smem + (c_begin & 1) * IMG);
-        if (nck > 2) issue(c_begin + 2);
-      }
-      __syncthreads();                 // start of iteration 0
-      if (nck > 0) __syncthreads();    // iteration 0: the other group commits
-      int i = 1;
-      for (; i + 3 < nck; i += 2) {    // steady state: no branches between the loads and their use
-        commit_issue(c_begin + i + 1, smem + ((c_begin + i + 1) & 1) * IMG, c_begin + i + 3);
-        __syncthreads();
-        __syncthreads();
-      }
-      for (; i < nck; ++i) {
-        if (((i & 1) == 1) && i + 1 < nck) commit(c_begin + i + 1, smem + ((c_begin + i + 1) & 1) * IMG);
-        __syncthreads();
-      }
-    } else {
-      if (nck > 1) issue(c_begin + 1);
-      lds_setup();
+      commit(c_begin + i + 2, bufof(i + 2), RA);
+      issue(c_begin + i + 4, RA);
       __syncthreads();
-      __syncthreads();                 // start of iteration 0
-      int i = 0;
-      for (; i + 3 < nck; i += 2) {
-        commit_issue(c_begin + i + 1, smem + ((c_begin + i + 1) & 1) * IMG, c_begin + i + 3);
-        __syncthreads();
-        __syncthreads();
+    }
+    for (; i < nck; ++i) {
+      if (i + 1 < nck) {
+        if ((i + 1) & 1) commit(c_begin + i + 1, bufof(i + 1), RB); else commit(c_begin + i + 1, bufof(i + 1), RA);
+        if (i + 3 < nck) {
+          if ((i + 3) & 1) issue(c_begin + i + 3, RB); else issue(c_begin + i + 3, RA);
+        }
       }
-      for (; i < nck; ++i) {
-        if (((i & 1) == 0) && i + 1 < nck) commit(c_begin + i + 1, smem + ((c_begin + i + 1) & 1) * IMG);
-        __syncthreads();
-      }
+      __syncthreads();
     }
   } else {
     // =========================== consumer waves ===========================
@@ -544,11 +501,11 @@ void d3_fwd_pick_tile(int H, int W, int np, int* th, int* tw, int* rg) {
     *th = np >= 3 ? 4 : 8;
   }
   // rows per staging lane group: 4 (conflict-free LDS writes) unless 2 saves a staging round
-  auto rounds = [&](int g) {
+  auto units = [&](int g) {
     const int qpg = 4 / g;
-    return (8 * ((*th + 2 + g - 1) / g) * ((*tw / 4 + qpg - 1) / qpg) + 255) / 256;
+    return 8 * ((*th + 2 + g - 1) / g) * ((*tw / 4 + qpg - 1) / qpg);
   };
-  *rg = rounds(2) < rounds(4) ? 2 : 4;
+  *rg = units(4) <= 512 ? 4 : 2;  // 512 producer threads, one unit each
 }
 
 template <int MPW, int NR, int NP, int DT>
@@ -576,8 +533,8 @@ int d3_fwd_launch(const D3Fwd& p, int N, int np, int dt, hipStream_t s) {
   const int npix = p.th * p.tw;
   const int qpg = 4 / p.rg;
   const int lane_units = 8 * ((p.th + 2 + p.rg - 1) / p.rg) * ((p.tw / 4 + qpg - 1) / qpg);
-  const int nr = (lane_units + 255) / 256;
-  if ((p.th + 2) * 16 > 256 || nr > 2 || (p.tw & 3) || (p.rg != 2 && p.rg != 4)) return -4;
+  const int nr = 1;
+  if ((p.th + 2) * 16 > 512 || lane_units > 512 || (p.tw & 3) || (p.rg != 2 && p.rg != 4)) return -4;
 #define D3_FWD(MPW_, NR_)                                                                         \
   do {                                                                                            \
     if (dt == D3_BF16) {                                                                          \
@@ -589,9 +546,9 @@ int d3_fwd_launch(const D3Fwd& p, int N, int np, int dt, hipStream_t s) {
       return d3_fwd_launch_t<MPW_, NR_, 2, D3_F16>(p, N, s);                                      \
     }                                                                                             \
   } while (0)
-  if (npix <= 320 && nr == 1) D3_FWD(5, 1);
-  if (npix <= 320) D3_FWD(5, 2);
-  if (npix <= 640) D3_FWD(10, 2);
+  (void)nr;
+  if (npix <= 320) D3_FWD(5, 1);
+  if (npix <= 640) D3_FWD(10, 1);
 #undef D3_FWD
   return -4;
 }
@@ -645,162 +602,157 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
   for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (producer) {
-    const int pgroup = (wave - 4) >> 2;  // 0: tiles t0+1, +3, ...   1: tiles t0, +2, ...
-    const int ptid = tid & 255;
-    // z staging plan (tile-invariant part): lane-unit = 2 octets x RG rows x (4/RG) quads
+    // All 8 producer waves work on EVERY tile: thread -> one staging unit (8 channels x 4 pixels, or a halo pair):
+    //   ptid   0..255  z unit      (2 octets x RG rows x quads; 240 used for the 4x80 tile)
+    //   ptid 256..415  dY unit     (2 octets x 4 rows x 20 quads)
+    //   ptid 416..511  z halo unit (row, side, channel pair)
+    // Two register sets hold the tiles of even / odd iteration, so a tile's loads stay in flight for two iterations.
+    const int ptid = tid - 256;
     const int nq = p.tw >> 2;
     const int rgs = p.rg == 2 ? 1 : 2;
     const int qpg = 4 >> rgs;
     const int nqg = (nq + qpg - 1) / qpg;
     const int nrg = (rows + p.rg - 1) >> rgs;
-    int z_r, z_q, z_o;
-    bool z_ex;
-    {
+    const int kind = ptid < 256 ? 0 : (ptid < 416 ? 1 : 2);
+    int u_r = 0, u_q = 0, u_o = 0, u_lds = 0, h_side = 0;
+    bool u_ex = false;
+    if (kind == 0) {
       const int lu = ptid;
-      z_o = lu & 1;
+      u_o = lu & 1;
       const int rr = (lu >> 1) & (p.rg - 1), qq = (lu >> (1 + rgs)) & (qpg - 1), u = lu >> 3;
       const int R = u / nqg;
-      z_q = (u - R * nqg) * qpg + qq;
-      z_r = (R << rgs) + rr;
-      z_ex = (R < nrg) && (z_r < rows) && (z_q < nq);
+      u_q = (u - R * nqg) * qpg + qq;
+      u_r = (R << rgs) + rr;
+      u_ex = (R < nrg) && (u_r < rows) && (u_q < nq);
+      u_lds = ((u_ex ? u_r : 0) * P + 1 + 4 * (u_ex ? u_q : 0)) * 32 + u_o * 16;
+    } else if (kind == 1) {
+      const int yu = ptid - 256;
+      u_o = yu & 1;
+      const int y2 = yu >> 1;
+      u_r = y2 / nq;
+      u_q = y2 - u_r * nq;
+      u_ex = u_r < p.th;
+      u_lds = ((u_ex ? u_r : 0) * p.tw + 4 * u_q) * 32 + u_o * 16;
+    } else {
+      const int hu = ptid - 416;
+      u_o = hu & 7;  // channel pair
+      h_side = (hu >> 3) & 1;
+      u_r = hu >> 4;
+      u_ex = u_r < rows;
+      u_lds = ((u_ex ? u_r : 0) * P + (h_side ? p.tw + 1 : 0)) * 32 + u_o * 4;
     }
-    const int z_lds = ((z_ex ? z_r : 0) * P + 1 + 4 * (z_ex ? z_q : 0)) * 32 + z_o * 16;
-    // halo columns: (row, side, channel pair)
-    const int h_cp = ptid & 7, h_side = (ptid >> 3) & 1, h_r = ptid >> 4;
-    const bool h_ex = h_r < rows;
-    const int h_lds = ((h_ex ? h_r : 0) * P + (h_side ? p.tw + 1 : 0)) * 32 + h_cp * 4;
-    // dY staging: lane-unit = (octet, row-of-4-in-tile?, quad): 2 x th x nq units
-    const int y_o = ptid & 1, y_u = ptid >> 1;
-    const int y_r = y_u / nq, y_q = y_u - y_r * nq;
-    const bool y_ex = y_r < p.th;
-    const int y_lds = ((y_ex ? y_r : 0) * p.tw + 4 * y_q) * 32 + y_o * 16;
-
-    float4 zreg[8], yreg[8];
-    float hreg[2];
-    unsigned okbits = 0;  // validity of the in-flight tile: bit0 z unit, bit1 halo unit, bit2 dY unit
-    auto issue = [&](int t) __attribute__((always_inline)) {
+    // Every thread issues the SAME 8 dwordx4 loads per tile from (kind base) + choff[cc] + per-tile pixel offset: no
+    // branches around the loads, so the wait counters stay exact (a join of paths with different load counts makes the
+    // compiler wait for the youngest loads too, which would halve the prefetch distance).
+    int choff[8];
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) {
+      const int ch = kind == 0 ? cb + u_o * 8 + cc : (kind == 1 ? min(u_o * 8 + cc, p.Cout - 1) : cb + 2 * u_o + (cc & 1));
+      choff[cc] = ch * p.cs;
+    }
+    const float* kbase = kind == 1 ? p.dY : p.S;
+    const long long kns = kind == 1 ? (long long)p.Cout * p.cs : p.ns;
+    float4 regA[8], regB[8];
+    bool okA = false, okB = false;
+    auto issue = [&](int t, float4 (&reg)[8], bool& okf) __attribute__((always_inline)) {
       const int n = t / tiles, tl = t - n * tiles;
       const int tile_y = tl / p.tiles_x, tile_x = tl - tile_y * p.tiles_x;
       const int gy0 = tile_y * p.th, gx0 = tile_x * p.tw;
-      const float* base = p.S + (long long)n * p.ns + (long long)cb * p.cs;
-      {
-        const int iy = gy0 - 1 + z_r, ix = gx0 + 4 * z_q;
-        const bool ok = z_ex && iy >= 0 && iy < p.H && ix < p.W;
-        const float* src = base + (long long)(z_o * 8) * p.cs + (ok ? iy * p.W + ix : 0);
+      int iy, ix;
+      bool ok;
+      if (kind == 0) {
+        iy = gy0 - 1 + u_r;
+        ix = gx0 + 4 * u_q;
+        ok = u_ex && iy >= 0 && iy < p.H && ix < p.W;
+      } else if (kind == 1) {
+        iy = gy0 + u_r;
+        ix = gx0 + 4 * u_q;
+        ok = u_ex && iy < p.H && ix < p.W;
+      } else {  // halo pixel: the aligned quad that holds it (left: last element of the quad, right: first)
+        iy = gy0 - 1 + u_r;
+        const int hx = h_side ? gx0 + p.tw : gx0 - 1;
+        ok = u_ex && iy >= 0 && iy < p.H && hx >= 0 && hx < p.W;
+        ix = h_side ? hx : hx - 3;
+      }
+      const float* src = kbase + (long long)n * kns + (ok ? iy * p.W + ix : 0);
+#ifdef RLN_DIAG
+      if (!(p.dbg & 1))
+#endif
 #pragma unroll
-        for (int cc = 0; cc < 8; ++cc) zreg[cc] = *reinterpret_cast<const float4*>(src + (long long)cc * p.cs);
-        okbits = ok ? 1u : 0u;
-      }
-      {
-        const int iy = gy0 - 1 + h_r, ix = h_side ? gx0 + p.tw : gx0 - 1;
-        const bool ok = h_ex && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        const float* src = base + (long long)(2 * h_cp) * p.cs + (ok ? iy * p.W + ix : 0);
-        hreg[0] = src[0];
-        hreg[1] = src[p.cs];
-        okbits |= ok ? 2u : 0u;
-      }
-      {
-        const int iy = gy0 + y_r, ix = gx0 + 4 * y_q;
-        const bool ok = y_ex && iy < p.H && ix < p.W;
-        const float* src = p.dY + ((long long)n * p.Cout) * p.cs + (ok ? iy * p.W + ix : 0);
-#pragma unroll
-        for (int cc = 0; cc < 8; ++cc) {
-          const int ch = min(y_o * 8 + cc, p.Cout - 1);
-          yreg[cc] = *reinterpret_cast<const float4*>(src + (long long)ch * p.cs);
-        }
-        okbits |= ok ? 4u : 0u;
-      }
+      for (int cc = 0; cc < 8; ++cc) reg[cc] = *reinterpret_cast<const float4*>(src + choff[cc]);
+      okf = ok;
     };
-    auto commit = [&](int buf) __attribute__((always_inline)) {
+    auto commit = [&](int buf, const float4 (&reg)[8], bool okf) __attribute__((always_inline)) {
       unsigned char* zb = zbuf + buf * ZB;
       unsigned char* yb = ybuf + buf * YB;
-      if (z_ex) {  // z: BN + ReLU, zero outside the picture
-        const float* ab = abtab + z_o * 8;
-        const bool ok = okbits & 1u;
-#pragma unroll
-        for (int px = 0; px < 4; ++px) {
-          unsigned parts[4][NP];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float4 u0 = zreg[2 * k], u1 = zreg[2 * k + 1];
-            const float x0 = px == 0 ? u0.x : px == 1 ? u0.y : px == 2 ? u0.z : u0.w;
-            const float x1 = px == 0 ? u1.x : px == 1 ? u1.y : px == 2 ? u1.z : u1.w;
-            const float z0 = ok ? fmaxf(fmaf(ab[2 * k], x0, ab[16 + 2 * k]), 0.f) : 0.f;
-            const float z1 = ok ? fmaxf(fmaf(ab[2 * k + 1], x1, ab[16 + 2 * k + 1]), 0.f) : 0.f;
-            split2<DT, NP>(z0, z1, parts[k]);
-          }
-#pragma unroll
-          for (int pt = 0; pt < NP; ++pt)
-            *reinterpret_cast<uint4*>(zb + pt * PLZ + z_lds + px * 32) =
-                make_uint4(parts[0][pt], parts[1][pt], parts[2][pt], parts[3][pt]);
-        }
-      }
-      if (h_ex) {
-        const bool ok = okbits & 2u;
-        const float z0 = ok ? fmaxf(fmaf(abtab[2 * h_cp], hreg[0], abtab[16 + 2 * h_cp]), 0.f) : 0.f;
-        const float z1 = ok ? fmaxf(fmaf(abtab[2 * h_cp + 1], hreg[1], abtab[16 + 2 * h_cp + 1]), 0.f) : 0.f;
+      if (!u_ex) return;
+#ifdef RLN_DIAG
+      if (p.dbg & 2) return;
+#endif
+      if (kind == 2) {
+        const float x0 = h_side ? reg[0].x : reg[0].w, x1 = h_side ? reg[1].x : reg[1].w;
+        const float z0 = okf ? fmaxf(fmaf(abtab[2 * u_o], x0, abtab[16 + 2 * u_o]), 0.f) : 0.f;
+        const float z1 = okf ? fmaxf(fmaf(abtab[2 * u_o + 1], x1, abtab[16 + 2 * u_o + 1]), 0.f) : 0.f;
         unsigned parts[NP];
         split2<DT, NP>(z0, z1, parts);
 #pragma unroll
-        for (int pt = 0; pt < NP; ++pt) *reinterpret_cast<unsigned*>(zb + pt * PLZ + h_lds) = parts[pt];
+        for (int pt = 0; pt < NP; ++pt) *reinterpret_cast<unsigned*>(zb + pt * PLZ + u_lds) = parts[pt];
+        return;
       }
-      if (y_ex) {  // dY: plain split, zero outside the picture and beyond Cout
-        const bool ok = okbits & 4u;
+      // kind 0: z = relu(a*x + b) of 8 channels x 4 pixels; kind 1: dY as it is (zero beyond Cout); zero outside
+      float av[8], bv[8];
 #pragma unroll
-        for (int px = 0; px < 4; ++px) {
-          unsigned parts[4][NP];
+      for (int cc = 0; cc < 8; ++cc) {
+        av[cc] = kind == 0 ? abtab[u_o * 8 + cc] : ((u_o * 8 + cc < p.Cout) ? 1.f : 0.f);
+        bv[cc] = kind == 0 ? abtab[16 + u_o * 8 + cc] : 0.f;
+      }
+      unsigned char* dst = (kind == 0 ? zb : yb) + u_lds;
+      const int plane = kind == 0 ? PLZ : PLY;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float4 u0 = yreg[2 * k], u1 = yreg[2 * k + 1];
-            float x0 = px == 0 ? u0.x : px == 1 ? u0.y : px == 2 ? u0.z : u0.w;
-            float x1 = px == 0 ? u1.x : px == 1 ? u1.y : px == 2 ? u1.z : u1.w;
-            if (!ok || y_o * 8 + 2 * k >= p.Cout) x0 = 0.f;
-            if (!ok || y_o * 8 + 2 * k + 1 >= p.Cout) x1 = 0.f;
-            split2<DT, NP>(x0, x1, parts[k]);
+      for (int px = 0; px < 4; ++px) {
+        unsigned parts[4][NP];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float4 u0 = reg[2 * k], u1 = reg[2 * k + 1];
+          const float x0 = px == 0 ? u0.x : px == 1 ? u0.y : px == 2 ? u0.z : u0.w;
+          const float x1 = px == 0 ? u1.x : px == 1 ? u1.y : px == 2 ? u1.z : u1.w;
+          float z0 = fmaf(av[2 * k], x0, bv[2 * k]), z1 = fmaf(av[2 * k + 1], x1, bv[2 * k + 1]);
+          if (kind == 0) {
+            z0 = fmaxf(z0, 0.f);
+            z1 = fmaxf(z1, 0.f);
           }
-#pragma unroll
-          for (int pt = 0; pt < NP; ++pt)
-            *reinterpret_cast<uint4*>(yb + pt * PLY + y_lds + px * 32) =
-                make_uint4(parts[0][pt], parts[1][pt], parts[2][pt], parts[3][pt]);
+          split2<DT, NP>(okf ? z0 : 0.f, okf ? z1 : 0.f, parts[k]);
         }
+#pragma unroll
+        for (int pt = 0; pt < NP; ++pt)
+          *reinterpret_cast<uint4*>(dst + pt * plane + px * 32) =
+              make_uint4(parts[0][pt], parts[1][pt], parts[2][pt], parts[3][pt]);
       }
     };
-    // iteration i (consumers multiply tile t0+i): the group with (i & 1) == pgroup commits tile i+1, re-issues i+3;
-    // group 1 also stages the first tile
+    // tile t0+i lives in set i & 1.  Iteration i (consumers multiply tile i): commit tile i+1, refill its set with i+3.
     __syncthreads();  // affine table
-    if (pgroup == 1) {
-      if (nt > 0) {
-        issue(t0);
-        commit(0);
-        if (nt > 2) issue(t0 + 2);
+    if (nt > 0) issue(t0, regA, okA);
+    if (nt > 1) issue(t0 + 1, regB, okB);
+    if (nt > 0) commit(0, regA, okA);
+    if (nt > 2) issue(t0 + 2, regA, okA);
+    __syncthreads();  // first tile staged
+    int i = 0;
+    for (; i + 4 < nt; i += 2) {  // steady state, two iterations per trip, no branches around the loads
+      commit(1, regB, okB);
+      issue(t0 + i + 3, regB, okB);
+      __syncthreads();
+      commit(0, regA, okA);
+      issue(t0 + i + 4, regA, okA);
+      __syncthreads();
+    }
+    for (; i < nt; ++i) {
+      if (i + 1 < nt) {
+        if ((i + 1) & 1) commit(1, regB, okB); else commit(0, regA, okA);
+        if (i + 3 < nt) {
+          if ((i + 3) & 1) issue(t0 + i + 3, regB, okB); else issue(t0 + i + 3, regA, okA);
+        }
       }
       __syncthreads();
-      if (nt > 0) __syncthreads();
-      int i = 1;
-      for (; i + 3 < nt; i += 2) {
-        commit((i + 1) & 1);
-        issue(t0 + i + 3);
-        __syncthreads();
-        __syncthreads();
-      }
-      for (; i < nt; ++i) {
-        if (((i & 1) == 1) && i + 1 < nt) commit((i + 1) & 1);
-        __syncthreads();
-      }
-    } else {
-      if (nt > 1) issue(t0 + 1);
-      __syncthreads();
-      int i = 0;
-      for (; i + 3 < nt; i += 2) {
-        commit((i + 1) & 1);
-        issue(t0 + i + 3);
-        __syncthreads();
-        __syncthreads();
-      }
-      for (; i < nt; ++i) {
-        if (((i & 1) == 0) && i + 1 < nt) commit((i + 1) & 1);
-        __syncthreads();
-      }
     }
   } else {
     // =========================== consumer waves ===========================
@@ -826,46 +778,47 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
     }
     __syncthreads();  // affine table
     __syncthreads();  // first tile staged
+    __builtin_amdgcn_s_setprio(2);  // the matrix waves win issue arbitration against the two staging waves of their SIMD
     for (int i = 0; i < nt; ++i) {
       const unsigned char* zb = zbuf + (i & 1) * ZB;
       const unsigned char* yb = ybuf + (i & 1) * YB;
+      // one straight sequence of KS x 9 (K-step, tap) steps with a DEPTH-deep read-ahead ring across K-step boundaries;
+      // a K-step a wave does not own runs with a zero dY fragment (adds nothing) so that all four waves share one code path
+      constexpr int DEPTH = 3, RING = DEPTH + 1;
+      const int STEPS = nks * 9;  // wave-uniform: 27 (waves 0, 1) or 18 (waves 2, 3)
+      uint4 af[2][NP], bfr[RING][NP];
+      auto load_a = [&](int k, uint4 (&dst)[NP]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int k = 0; k < KS; ++k) {
-        if (k < nks) {
-          uint4 af[NP];
-#pragma unroll
-          for (int pt = 0; pt < NP; ++pt) {
-            const uint2 lo = lds_tr16(yb + pt * PLY + ya[k][0]), hi = lds_tr16(yb + pt * PLY + ya[k][1]);
-            af[pt] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-          }
-          constexpr int DEPTH = 2, RING = DEPTH + 1;
-          uint4 bfr[RING][NP];
-#pragma unroll
-          for (int t = 0; t < DEPTH; ++t) {
-            const int toff = ((t / 3 - 1) * P + (t % 3 - 1)) * 32;
-#pragma unroll
-            for (int pt = 0; pt < NP; ++pt) {
-              const uint2 lo = lds_tr16(zb + pt * PLZ + za[k][0] + toff), hi = lds_tr16(zb + pt * PLZ + za[k][1] + toff);
-              bfr[t % RING][pt] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int t = 0; t < 9; ++t) {
-            if (t + DEPTH < 9) {
-              const int t1 = t + DEPTH;
-              const int toff = ((t1 / 3 - 1) * P + (t1 % 3 - 1)) * 32;
-#pragma unroll
-              for (int pt = 0; pt < NP; ++pt) {
-                const uint2 lo = lds_tr16(zb + pt * PLZ + za[k][0] + toff),
-                            hi = lds_tr16(zb + pt * PLZ + za[k][1] + toff);
-                bfr[t1 % RING][pt] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-              }
-            }
-            acc[t] = mfma_split<DT, NP>(af, bfr[t % RING], acc[t]);
-            __builtin_amdgcn_sched_barrier(0);
-          }
+        for (int pt = 0; pt < NP; ++pt) {
+          const uint2 lo = lds_tr16(yb + pt * PLY + ya[k][0]), hi = lds_tr16(yb + pt * PLY + ya[k][1]);
+          dst[pt] = make_uint4(lo.x, lo.y, hi.x, hi.y);
         }
+      };
+      auto load_b = [&](int st, uint4 (&dst)[NP]) __attribute__((always_inline)) {
+        const int k = st / 9, t = st - k * 9;
+        const int toff = ((t / 3 - 1) * P + (t % 3 - 1)) * 32;
+#pragma unroll
+        for (int pt = 0; pt < NP; ++pt) {
+          const uint2 lo = lds_tr16(zb + pt * PLZ + za[k][0] + toff), hi = lds_tr16(zb + pt * PLZ + za[k][1] + toff);
+          dst[pt] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+      };
+      load_a(0, af[0]);
+#pragma unroll
+      for (int st = 0; st < DEPTH; ++st) load_b(st, bfr[st % RING]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int st = 0; st < KS * 9; ++st) {
+        const int k = st / 9, t = st - k * 9;
+#ifdef RLN_DIAG
+        if (p.dbg & 4) continue;
+#endif
+        if (st < STEPS) {  // wave-uniform
+          if (st + DEPTH < KS * 9) load_b(st + DEPTH, bfr[(st + DEPTH) % RING]);  // past the wave's steps: clamped, unused
+          if (t == 9 - DEPTH && k + 1 < KS) load_a(k + 1, af[(k + 1) & 1]);
+          acc[t] = mfma_split<DT, NP>(af[k & 1], bfr[st % RING], acc[t]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
       __syncthreads();
     }

@@ -1381,6 +1381,9 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
       g.partial = c->wpartial;
       if (d3_wgrad_supported(g)) {  // transposed-read 16-bit MFMA kernel
         d3_wgrad_plan(lv.H, lv.W, N, o.cin, &g);
+#ifdef RLN_DIAG
+        if (getenv("RLN_D3_DBG")) g.dbg = atoi(getenv("RLN_D3_DBG"));
+#endif
         {
           const double wflops = 2.0 * o.cout * o.cin * 9.0 * plane * N;
           const double wbytes = 4.0 * N * ((double)o.cout + o.cin) * plane;
