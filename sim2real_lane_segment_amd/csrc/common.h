@@ -3,7 +3,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
+
 namespace rln {
+
+// Experiment switches (RLN_* environment variables) exist in diagnostic builds only (build.sh -DRLN_DIAG): the shipped
+// library answers "unset" at compile time, so every switch folds away and no launch path reads the environment.
+#ifdef RLN_DIAG
+inline const char* rln_env(const char* name) { return std::getenv(name); }
+#else
+constexpr const char* rln_env(const char*) { return nullptr; }
+#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

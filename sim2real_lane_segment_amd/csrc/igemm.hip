@@ -711,7 +711,7 @@ static int launch_v(const IgemmParams& p, int N, hipStream_t stream) {
                               C::LDS_BYTES);
     (void)hipGetLastError();
     attr_done = true;
-    if (getenv("RLN_DEBUG_OCC")) {
+    if (rln_env("RLN_DEBUG_OCC")) {
       int nb = -1;
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 256, C::LDS_BYTES);
       fprintf(stderr, "[rln] igemm_k<KS%d NT%d PRO%d EPI%d %dx%d CLS%d V4%d> lds %d B -> %d blocks/CU\n", KS, NT, PRO, EPI,
@@ -720,7 +720,7 @@ static int launch_v(const IgemmParams& p, int N, hipStream_t stream) {
   }
   dim3 grid((unsigned)(p.ncls * p.tiles_x * p.tiles_y),
             (unsigned)(((p.J + NT * 16 - 1) / (NT * 16)) * (p.ksplit > 1 ? p.ksplit : 1)), (unsigned)N);
-  static const int dbg = getenv("RLN_DBG") ? atoi(getenv("RLN_DBG")) : 0;
+  static const int dbg = rln_env("RLN_DBG") ? atoi(rln_env("RLN_DBG")) : 0;
   if (dbg) {
     IgemmParams q = p;
     q.dbg = dbg;
@@ -740,7 +740,7 @@ static int launch_t(const IgemmParams& p, int N, hipStream_t stream) {
   if constexpr (PRO != PRO_S2D) {
     // measured: on the small tiles the 16-byte staging path is not faster than the scalar one (the tile-with-halo
     // pattern is bound by 128-byte line requests, not by instruction count); it is used by the strip tiles only.
-    static const bool want_v4 = getenv("RLN_V4_ALL") != nullptr;
+    static const bool want_v4 = rln_env("RLN_V4_ALL") != nullptr;
     const bool v4 = want_v4 && (p.Win % 4 == 0) && (p.in_cs % 4 == 0) && (p.in_ns % 4 == 0) &&
                     ((((uintptr_t)p.in) & 15) == 0);
     if (v4) return launch_v<KS, NT, PRO, EPI, TH, TW, CLS, true>(p, N, stream);
@@ -781,8 +781,8 @@ void igemm_tile_dims(IgemmKind kind, int tile, int* th, int* tw) {
 
 // strip tiles need the 16-byte staging path: W % 4 == 0 and aligned planes (checked by the caller)
 int igemm_pick_strip_tile(int gw) {
-  if (getenv("RLN_NO_STRIP")) return -1;
-  static const int mode = getenv("RLN_STRIP_MODE") ? atoi(getenv("RLN_STRIP_MODE")) : 0;
+  if (rln_env("RLN_NO_STRIP")) return -1;
+  static const int mode = rln_env("RLN_STRIP_MODE") ? atoi(rln_env("RLN_STRIP_MODE")) : 0;
   if (mode == 1) return (gw == 160 || gw == 80) ? 4 : -1;  // experiment: 4x80 everywhere
   if (mode == 2) return gw == 160 ? 4 : (gw == 80 ? 3 : -1);
   if (mode == 3) return gw == 160 ? 2 : (gw == 80 ? 3 : -1);
@@ -828,7 +828,7 @@ int igemm_launch(IgemmKind kind, int tile, const IgemmParams& p, int N, hipStrea
     case IG_S2D3: {
       // output-channel tiles per block.  80 channels: 2 x 48 wastes 17 % of the MFMA columns (2 x 64: 38 %) and keeps
       // two blocks per CU; 1 x 80 fits only one block per CU and measured slower (1.72 vs 1.40 ms/step).
-      static const int force = getenv("RLN_S2D_NT") ? atoi(getenv("RLN_S2D_NT")) : 0;
+      static const int force = rln_env("RLN_S2D_NT") ? atoi(rln_env("RLN_S2D_NT")) : 0;
       const int waste4 = (p.J + 63) / 64 * 64 - p.J, waste3 = (p.J + 47) / 48 * 48 - p.J;
       const int nt = force ? force : (waste3 < waste4 ? 3 : 4);
       if (nt == 5) return launch_t<3, 5, PRO_S2D, EPI_STORE, 8, 16>(p, N, stream);
@@ -1115,7 +1115,7 @@ static int dgrad_loop_launch_t(const IgemmParams& p, int N, hipStream_t stream) 
                               96 * 1024);
     (void)hipGetLastError();
     attr_done = true;
-    if (getenv("RLN_DEBUG_OCC")) {
+    if (rln_env("RLN_DEBUG_OCC")) {
       int nb = -1;
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 256, LDS);
       fprintf(stderr, "[rln] dgrad_loop_k<%dx%d> lds %d B -> %d blocks/CU\n", TH, TW, LDS, nb);
@@ -1127,9 +1127,9 @@ static int dgrad_loop_launch_t(const IgemmParams& p, int N, hipStream_t stream) 
   int split = 1;
   if (base_blocks < 512) split = (int)std::min<long long>((512 + base_blocks - 1) / base_blocks, (long long)nct);
   dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)split, (unsigned)N);
-  static const int dbg = getenv("RLN_DBG") ? atoi(getenv("RLN_DBG")) : 0;
+  static const int dbg = rln_env("RLN_DBG") ? atoi(rln_env("RLN_DBG")) : 0;
   if ((dbg & 64) && TH == 8 && p.GW >= 160) {  // diagnostic build: phase stamps / ablations of the level-0 launches
-    static const int abl = getenv("RLN_DG_ABL") ? atoi(getenv("RLN_DG_ABL")) : 0;
+    static const int abl = rln_env("RLN_DG_ABL") ? atoi(rln_env("RLN_DG_ABL")) : 0;
     IgemmParams q = p;
     q.dbg = 16 | abl;
     q.dbg_out = igemm_debug_buffer();
@@ -1667,7 +1667,7 @@ static int wlaunch_q(const WgradParams& p, hipStream_t stream) {
                               C::LDS_BYTES);
     (void)hipGetLastError();
     attr_done = true;
-    if (getenv("RLN_DEBUG_OCC")) {
+    if (rln_env("RLN_DEBUG_OCC")) {
       int nb = -1;
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 256, C::LDS_BYTES);
       fprintf(stderr, "[rln] wgrad_dense_q_k<%dx%d,%d> lds %d B -> %d blocks/CU\n", TH, TW, NCH_, C::LDS_BYTES, nb);
@@ -1688,7 +1688,7 @@ static int wlaunch_t(const WgradParams& p, hipStream_t stream) {
                               C::LDS_BYTES);
     (void)hipGetLastError();
     attr_done = true;
-    if (getenv("RLN_DEBUG_OCC")) {
+    if (rln_env("RLN_DEBUG_OCC")) {
       int nb = -1;
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 256, C::LDS_BYTES);
       fprintf(stderr, "[rln] wgrad_k<KS%d MT%d PRO%d SA%d %dx%d> lds %d B -> %d blocks/CU\n", KS, MT, PRO, (int)SHIFT_A, TH,
@@ -1698,7 +1698,7 @@ static int wlaunch_t(const WgradParams& p, hipStream_t stream) {
   const int Mc = SHIFT_A ? p.Vc : p.Uc;
   const int Nc = SHIFT_A ? p.Uc : p.Vc;
   dim3 grid((unsigned)p.nchunks, (unsigned)((Mc + C::MCH - 1) / C::MCH), (unsigned)((Nc + 63) / 64));
-  static const int dbg = getenv("RLN_DBG") ? atoi(getenv("RLN_DBG")) : 0;
+  static const int dbg = rln_env("RLN_DBG") ? atoi(rln_env("RLN_DBG")) : 0;
   if (dbg & (256 | 128)) {
     WgradParams q = p;
     if (dbg & 256) q.xcd_remap = 1;
@@ -1734,12 +1734,12 @@ void wgrad_block_dims(WgradKind kind, int* m_per_block, int* n_per_block) {
 
 // V channels per block of the 16-byte staging kernel the dense launch will use (0: generic kernel, 64 per block)
 int wgrad_dense_q_channels(const WgradParams& p) {
-  static const bool noq = getenv("RLN_NO_WGQ") != nullptr;
-  static const int nch = getenv("RLN_WGQ_NCH") ? atoi(getenv("RLN_WGQ_NCH")) : 16;  // measured: 16 > 32 > 64 (+0.8 %, +4 %)
+  static const bool noq = rln_env("RLN_NO_WGQ") != nullptr;
+  static const int nch = rln_env("RLN_WGQ_NCH") ? atoi(rln_env("RLN_WGQ_NCH")) : 16;  // measured: 16 > 32 > 64 (+0.8 %, +4 %)
   const bool al = ((reinterpret_cast<uintptr_t>(p.u) | reinterpret_cast<uintptr_t>(p.v)) & 15) == 0;
   const bool q = !noq && al && p.Uc <= 16 && (p.GW % 4) == 0 && p.Wv == p.GW && p.Hv == p.GH &&
                  (p.u_cs % 4) == 0 && (p.v_cs % 4) == 0 && (p.u_ns % 4) == 0 && (p.v_ns % 4) == 0;
-  static const int nch_wide = getenv("RLN_WGQ_NCH_WIDE") ? atoi(getenv("RLN_WGQ_NCH_WIDE")) : 0;  // levels >= 160 wide
+  static const int nch_wide = rln_env("RLN_WGQ_NCH_WIDE") ? atoi(rln_env("RLN_WGQ_NCH_WIDE")) : 0;  // levels >= 160 wide
   const int sel = (nch_wide && p.GW >= 160) ? nch_wide : nch;
   return q ? (sel == 64 ? 64 : (sel == 16 ? 16 : 32)) : 0;
 }

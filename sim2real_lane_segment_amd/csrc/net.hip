@@ -433,8 +433,8 @@ void level_dims(const rln_ctx* c, int h, int w, std::vector<int>& hs, std::vecto
 // input-channel loop is split over blocks.  The factor depends on the level's pixel count ONLY (not on the batch
 // size), so a sample's result does not depend on which batch it is evaluated in.
 int dense_fwd_split(int hw, int cin) {
-  static const int mid = getenv("RLN_SPLIT_MID") ? atoi(getenv("RLN_SPLIT_MID")) : 2;  // 512 < hw <= 1200 (measured: 2)
-  if (hw > 1200 || hw <= 0 || getenv("RLN_NO_SPLITK")) return 1;
+  static const int mid = rln_env("RLN_SPLIT_MID") ? atoi(rln_env("RLN_SPLIT_MID")) : 2;  // 512 < hw <= 1200 (measured: 2)
+  if (hw > 1200 || hw <= 0 || rln_env("RLN_NO_SPLITK")) return 1;
   if (hw > 512 && mid <= 1) return 1;
   const int nchunk = (cin + 15) / 16;
   const int want = hw <= 128 ? 8 : (hw <= 512 ? 4 : mid);
@@ -694,7 +694,7 @@ int finalize_stats(rln_ctx* c, int level, int ch_off, int J, long long nblk, hip
   const double count = (double)c->N * lv.H * lv.W;
   const int64_t so = lv.stat_off + ch_off;
   ProfScope ps(c, PC_BN, 0, 0, s);
-  static const bool nofuse = getenv("RLN_NO_BNFUSE") != nullptr;
+  static const bool nofuse = rln_env("RLN_NO_BNFUSE") != nullptr;
   if (!nofuse && k >= 0 && (size_t)(k + 1) < c->ops.size()) {
     const Op& nx = c->ops[(size_t)k + 1];
     if ((nx.type == OP_DENSE || nx.type == OP_TD) && nx.src_level == level && nx.in_off <= ch_off &&
@@ -729,7 +729,7 @@ int prep_bn(rln_ctx* c, const Op& o, int training, hipStream_t s, long long k = 
 }
 
 static bool convt_fused() {
-  static const bool off = getenv("RLN_NO_CONVT4") != nullptr;
+  static const bool off = rln_env("RLN_NO_CONVT4") != nullptr;
   return !off;
 }
 
@@ -1025,7 +1025,7 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
     const float* nscale = (o.drop_ch >= 0) ? (c->masks + (size_t)N * o.drop_ch) : nullptr;
     RLN_TRY(finalize_grad_range(c, o.dst_level, o.out_off, o.cout, nscale, &rows, s));
     // dense layers on one stream: the three small reductions of the layer run as ONE launch after the weight gradient
-    static const bool no_tail = getenv("RLN_NO_TAIL") != nullptr;
+    static const bool no_tail = rln_env("RLN_NO_TAIL") != nullptr;
     const bool fuse_tail = o.type == OP_DENSE && !c->use_side && !no_tail;
     DenseTail tail;
     memset(&tail, 0, sizeof(tail));
@@ -1382,7 +1382,7 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
       if (d3_wgrad_supported(g)) {  // transposed-read 16-bit MFMA kernel
         d3_wgrad_plan(lv.H, lv.W, N, o.cin, &g);
 #ifdef RLN_DIAG
-        if (getenv("RLN_D3_DBG")) g.dbg = atoi(getenv("RLN_D3_DBG"));
+        if (rln_env("RLN_D3_DBG")) g.dbg = atoi(rln_env("RLN_D3_DBG"));
 #endif
         {
           const double wflops = 2.0 * o.cout * o.cin * 9.0 * plane * N;
@@ -1722,7 +1722,7 @@ int rln_backward(rln_ctx* c, float loss_scale, int seg_begin, int seg_end, void*
   const int N = c->N;
   // measured on MI355X: no gain (the kernels' LDS footprints do not co-reside on a CU and both are bound by the
   // memory system), so the concurrent weight-gradient stream is opt-in.
-  if (!c->side && getenv("RLN_SIDE_STREAM")) {
+  if (!c->side && rln_env("RLN_SIDE_STREAM")) {
     hipError_t e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
     for (int b = 0; b < 2 && e == hipSuccess; ++b) {
       e = hipEventCreateWithFlags(&c->ev_dy[b], hipEventDisableTiming);
@@ -1898,7 +1898,7 @@ int rln_op_dense3_fwd(const float* x, int n, int cin, int x_ctot, int x_coff, in
   p.wpk = packed;
   p.stat_partial = partial;
 #ifdef RLN_DIAG
-  if (getenv("RLN_D3_DBG")) p.dbg = atoi(getenv("RLN_D3_DBG"));
+  if (rln_env("RLN_D3_DBG")) p.dbg = atoi(rln_env("RLN_D3_DBG"));
 #endif
   RLN_TRY(d3_fwd_launch(p, n, parts, dtype, s));
   if (stats) RLN_TRY(reduce_rows(partial, nblk, (long long)cout * 2, stats, s));

@@ -57,8 +57,11 @@ def parse_dense_arith(text):
 
 
 # Arithmetic of the dense 3x3 layers used by every new Engine unless the caller passes dense_arith= (include/rln.h:
-# rln_set_dense_arith).  RLN_DENSE_ARITH overrides it for experiments, e.g. "fp32,fp32" or "f16x2,bf16x2".
-DEFAULT_DENSE_ARITH = parse_dense_arith(os.environ["RLN_DENSE_ARITH"]) if os.environ.get("RLN_DENSE_ARITH") else None
+# rln_set_dense_arith): forward on f16 operands split into 2 parts (3 products, ~2^-22: the accuracy class of the exact
+# fp32 MFMA chain, tools/dense3_precision.py), backward on bf16 x 2 parts (gradients need bf16's exponent range).
+# Storage and accumulation are fp32 in every mode.  "fp32,fp32" selects the exact-fp32 MFMA kernels of round 1.
+# RLN_DENSE_ARITH overrides the default for experiments.
+DEFAULT_DENSE_ARITH = parse_dense_arith(os.environ.get("RLN_DENSE_ARITH") or "f16x2,bf16x2")
 
 
 def _ptr(t: Optional[torch.Tensor]):

@@ -1,15 +1,16 @@
 """End-to-end parity (-m gpu): the HIP path through the C ABI against (a) the golden vectors generated
 from the reference's own code and (b) the CPU oracle on the same seeded inputs.
 
-Tolerances (fp32 path, BASELINE.json north_star): argmax masks bit-exact (outside the near-tie pixels the
-fixture lists), probabilities / scaled logits within 1e-3 absolute, gradients within 1e-3 relative to the
-tensor's scale on the reduced nets (every tensor, full comparison).
+Tolerances (fp32 storage / fp32 accumulation, BASELINE.json north_star): argmax masks bit-exact (outside the near-tie
+pixels the fixture lists; the actual flip count is printed and bounded), probabilities / scaled logits within 1e-3
+absolute, gradients within 1e-3 relative to the tensor's scale on the reduced nets (every tensor, full comparison).
 
-Gradient noise floor on FCDenseNet67: the reference path itself, run in fp32 and in fp64 on the CPU with the same
-inputs (N=2, 120x160, seed 700), differs by a median 9.5e-4 / worst 1.6e-2 max-relative error per gradient tensor
-(118 of 254 tensors above 1e-3) because fp32 rounding flips individual ReLU / max-pool decisions in a 60-layer net;
-norms agree to ~5e-4.  So on the full net gradients are held to 1e-2 L2-relative / 1e-2 in norm, while the
-forward quantities keep the 1e-3 / bit-exact-argmax bar."""
+Gradient noise floor on the full nets: the reference algorithm itself, run in fp32 and in fp64 on the CPU with the same
+inputs, differs per gradient tensor by an L2-relative median 1.5e-4 / max 2.4e-3 on FCDenseNet67 (2x120x160) and median
+1.4e-3 / max 2.6e-2 on FCDenseNet103 (2x64x96), because fp32 rounding flips individual ReLU / max-pool decisions in a
+60-100 layer net (tools/grad_noise_floor.py -> tests/golden/grad_noise_floor.json).  Full-net gradients are therefore
+held per tensor to max(8e-3, 20 x that tensor's noise floor) L2-relative (grad_l2_bar) and 1e-2 in norm, while the forward
+quantities keep the 1e-3 / bit-exact-argmax bar."""
 import os
 
 import numpy as np
@@ -39,6 +40,23 @@ def make_engine(cfg, st):
     eng = Engine(spec, device="cuda")
     eng.load_state(st)
     return eng
+
+
+_NOISE = None
+
+
+def grad_l2_bar(table, name):
+    """Per-tensor bar on the L2-relative gradient error: max(8e-3, 20 x the tensor's own fp32-vs-fp64 noise floor),
+    the latter measured on the CPU oracle by tools/grad_noise_floor.py and stored in tests/golden/grad_noise_floor.json
+    (FCDenseNet67 2x120x160: median 1.5e-4, max 2.4e-3; FCDenseNet103 2x64x96: median 1.4e-3, max 2.6e-2 -- rounding
+    flips individual ReLU / max-pool decisions in a 60-100 layer net).  Measured GPU-vs-oracle errors with the
+    default arithmetic (tools/grad_err_probe.py): FCDenseNet67 median 5.9e-4 / max 5.2e-3."""
+    global _NOISE
+    if _NOISE is None:
+        import json
+        with open(os.path.join(GOLDEN, "grad_noise_floor.json")) as f:
+            _NOISE = json.load(f)
+    return max(8e-3, 20.0 * _NOISE[table]["per_tensor"].get(name, 0.0))
 
 
 def rel_err(got, ref):
@@ -158,7 +176,10 @@ def test_fcd67_eval_masks_vs_golden(name):
     ref_mask = unpack_masks(z["mask_packed"], n * h * w)
     near = set(int(i) for i in z["near_tie_idx"])
     diff = torch.nonzero(mask != ref_mask).reshape(-1).tolist()
+    print(f"[{name}] argmax flips vs the reference mask: {len(diff)} of {n * h * w} pixels "
+          f"({len(near)} pixels have a reference top-2 gap < 2e-3; flips outside them: {sum(d not in near for d in diff)})")
     assert all(d in near for d in diff), f"{len(diff)} argmax flips, {sum(d not in near for d in diff)} outside near ties"
+    assert len(diff) == 0, "the kernels are deterministic: the measured flip count on these fixtures is zero"
     idx = torch.from_numpy(z["sample_idx"])
     got_p = probs.permute(0, 2, 3, 1).reshape(-1, 4).cpu()[idx].numpy()
     got_l = logits.permute(0, 2, 3, 1).reshape(-1, 4).cpu()[idx].numpy()
@@ -237,14 +258,17 @@ def test_config0_batch8_train_step_vs_oracle():
     assert abs(float(out[1]) * 100 - float(acc)) < 0.05
     np.testing.assert_allclose(probs.cpu().numpy(), probs_ref.numpy(), atol=1e-3)
     bad = []
+    worst = 0.0
     for k, g in grads.items():
         got = eng.grad_views[k].cpu()
         floor = 1e-5 * g.numel() ** 0.5
         err = float((got - g).abs().max()) / max(float(g.abs().max()), 1e-5)
         l2 = float((got - g).norm()) / max(float(g.norm()), floor)
         nerr = abs(float(got.norm()) - float(g.norm())) / max(float(g.norm()), floor)
-        if not (err < 1e-1 and l2 < 1e-2 and nerr < 1e-2):
+        worst = max(worst, l2)
+        if not (err < 1e-1 and l2 < grad_l2_bar("fcd67_2x120x160", k) and nerr < 1e-2):
             bad.append((k, err, l2, nerr))
+    print(f"[config0] worst L2-relative gradient error {worst:.2e}")
     assert not bad, f"{len(bad)} gradient tensors off: {bad[:10]}"
 
 
@@ -419,6 +443,6 @@ def test_named_variants_train_step_vs_oracle(variant):
         got = eng.grad_views[k].cpu()
         floor = 1e-5 * g.numel() ** 0.5
         l2 = float((got - g).norm()) / max(float(g.norm()), floor)
-        if not l2 < 1e-2:
+        if not l2 < grad_l2_bar(f"fcd{variant}_2x64x96", k):
             bad.append((k, l2))
     assert not bad, f"{len(bad)} gradient tensors off: {bad[:10]}"
