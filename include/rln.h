@@ -130,6 +130,13 @@ int rln_loss(rln_ctx* ctx, const float* probs, const int64_t* y, int n, int h, i
  * everything upstream of the features is negated. */
 int rln_entropy_loss(rln_ctx* ctx, const float* probs, int n, int h, int w, float lamda, float* out, void* stream);
 
+/* ---- differentiable module forward (TrainingBase.forward in user-written training code, SimpleTrain.py:15,
+ * MMETrainingModule.py:34-35): instead of one of the fused losses above, the caller hands in d(loss)/d(probabilities)
+ * [N][n_classes][H][W] for the probabilities the last TRAINING rln_forward returned; a following rln_backward
+ * differentiates through softmax, /T, classifier, F.normalize and the feature extractor.  The buffer must stay alive
+ * until rln_backward has run. */
+int rln_set_output_grad(rln_ctx* ctx, const float* dprobs, int n, int h, int w);
+
 /* torch.optim.SGD(momentum, nesterov=True, dampening=0, weight_decay) on a flat range, as configured in
  * MMETrainingModule.py:17-20 (one call per parameter group; first_step=1 initialises the momentum buffer). */
 int rln_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t count, float lr, float momentum,

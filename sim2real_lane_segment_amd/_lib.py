@@ -49,6 +49,7 @@ _PROTOS = {
     "rln_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                          c_void_p]),
     "rln_entropy_loss": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "rln_set_output_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int]),
     "rln_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_int, c_float,
                              c_void_p]),
     "rln_backward_segments": (c_int, [c_void_p]),

@@ -490,7 +490,7 @@ bool d3_fwd_supported(const D3Fwd& p) {
 // of (th+2)*W floats in HBM (no column halo; DRAM-page friendly), which streams about twice as fast as column tiles.
 void d3_fwd_pick_tile(int H, int W, int np, int* th, int* tw, int* rg) {
   (void)H;
-  if (W <= 160) {
+  if (W <= 160) {  // (8 x 80 column tiles at W = 160 were measured 4 % slower than 4 x 160 strips)
     *tw = W;
     const int cap = np >= 3 ? 320 : 640;  // pixels per tile (LDS: two image buffers)
     int t = cap / W;
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
     // All 8 producer waves work on EVERY tile: thread -> one staging unit (8 channels x 4 pixels, or a halo pair):
     //   ptid   0..255  z unit      (2 octets x RG rows x quads; 240 used for the 4x80 tile)
     //   ptid 256..415  dY unit     (2 octets x 4 rows x 20 quads)
-    //   ptid 416..511  z halo unit (row, side, channel pair)
+    //   ptid 416..511  z halo unit (row, side, channel quad)
     // Two register sets hold the tiles of even / odd iteration, so a tile's loads stay in flight for two iterations.
     const int ptid = tid - 256;
     const int nq = p.tw >> 2;
@@ -635,11 +635,11 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
       u_lds = ((u_ex ? u_r : 0) * p.tw + 4 * u_q) * 32 + u_o * 16;
     } else {
       const int hu = ptid - 416;
-      u_o = hu & 7;  // channel pair
-      h_side = (hu >> 3) & 1;
-      u_r = hu >> 4;
+      u_o = hu & 3;  // channel quad
+      h_side = (hu >> 2) & 1;
+      u_r = hu >> 3;
       u_ex = u_r < rows;
-      u_lds = ((u_ex ? u_r : 0) * P + (h_side ? p.tw + 1 : 0)) * 32 + u_o * 4;
+      u_lds = ((u_ex ? u_r : 0) * P + (h_side ? p.tw + 1 : 0)) * 32 + u_o * 8;
     }
     // Every thread issues the SAME 8 dwordx4 loads per tile from (kind base) + choff[cc] + per-tile pixel offset: no
     // branches around the loads, so the wait counters stay exact (a join of paths with different load counts makes the
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
     int choff[8];
 #pragma unroll
     for (int cc = 0; cc < 8; ++cc) {
-      const int ch = kind == 0 ? cb + u_o * 8 + cc : (kind == 1 ? min(u_o * 8 + cc, p.Cout - 1) : cb + 2 * u_o + (cc & 1));
+      const int ch = kind == 0 ? cb + u_o * 8 + cc : (kind == 1 ? min(u_o * 8 + cc, p.Cout - 1) : cb + 4 * u_o + (cc & 3));
       choff[cc] = ch * p.cs;
     }
     const float* kbase = kind == 1 ? p.dY : p.S;
@@ -690,13 +690,17 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
       if (p.dbg & 2) return;
 #endif
       if (kind == 2) {
-        const float x0 = h_side ? reg[0].x : reg[0].w, x1 = h_side ? reg[1].x : reg[1].w;
-        const float z0 = okf ? fmaxf(fmaf(abtab[2 * u_o], x0, abtab[16 + 2 * u_o]), 0.f) : 0.f;
-        const float z1 = okf ? fmaxf(fmaf(abtab[2 * u_o + 1], x1, abtab[16 + 2 * u_o + 1]), 0.f) : 0.f;
-        unsigned parts[NP];
-        split2<DT, NP>(z0, z1, parts);
+        float zv[4];
 #pragma unroll
-        for (int pt = 0; pt < NP; ++pt) *reinterpret_cast<unsigned*>(zb + pt * PLZ + u_lds) = parts[pt];
+        for (int k = 0; k < 4; ++k) {
+          const float x = h_side ? reg[k].x : reg[k].w;
+          zv[k] = okf ? fmaxf(fmaf(abtab[4 * u_o + k], x, abtab[16 + 4 * u_o + k]), 0.f) : 0.f;
+        }
+        unsigned pa[NP], pb2[NP];
+        split2<DT, NP>(zv[0], zv[1], pa);
+        split2<DT, NP>(zv[2], zv[3], pb2);
+#pragma unroll
+        for (int pt = 0; pt < NP; ++pt) *reinterpret_cast<uint2*>(zb + pt * PLZ + u_lds) = make_uint2(pa[pt], pb2[pt]);
         return;
       }
       // kind 0: z = relu(a*x + b) of 8 channels x 4 pixels; kind 1: dY as it is (zero beyond Cout); zero outside
@@ -852,18 +856,23 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
 
 bool d3_wgrad_supported(const D3Wgrad& p) {
   if (p.Cout < 1 || p.Cout > 16 || p.Cin < 1) return false;
-  if ((p.W % 80) != 0 || p.H < 4) return false;
+  if ((p.W % 40) != 0 || p.H < 4) return false;
   if ((p.cs & 3) || (p.ns & 3)) return false;
   if ((reinterpret_cast<uintptr_t>(p.S) & 15) || (reinterpret_cast<uintptr_t>(p.dY) & 15)) return false;
   return true;
 }
 
 void d3_wgrad_plan(int H, int W, int N, int Cin, D3Wgrad* p) {
-  p->th = 4;
-  p->tw = 80;
-  p->tiles_y = (H + 3) / 4;
-  p->tiles_x = (W + 79) / 80;
-  p->rg = 2;  // 6 staged rows = 3 bands of 2: one staging round of 240 lane-units
+  if (W % 80 == 0) {  // 320-pixel tiles: 4 x 80, or 8 x 40 where a row is not a multiple of 80
+    p->th = 4;
+    p->tw = 80;
+  } else {
+    p->th = 8;
+    p->tw = 40;
+  }
+  p->tiles_y = (H + p->th - 1) / p->th;
+  p->tiles_x = (W + p->tw - 1) / p->tw;
+  p->rg = 2;  // staged rows in bands of 2: 240 (4x80) / 200 (8x40) lane-units, one per z thread
   p->nchunks = (Cin + 15) / 16;
   const long long total = (long long)p->tiles_x * p->tiles_y * N;
   long long nr = std::max<long long>(1, 256 / p->nchunks);
@@ -890,7 +899,8 @@ static int d3_wgrad_launch_t(const D3Wgrad& p, hipStream_t s) {
 }
 
 int d3_wgrad_launch(const D3Wgrad& p, int np, int dt, hipStream_t s) {
-  if (!d3_wgrad_supported(p) || p.th != 4 || p.tw != 80 || p.rg != 2) return -4;
+  if (!d3_wgrad_supported(p) || p.th * p.tw != 320 || (p.tw != 80 && p.tw != 40) || p.rg != 2) return -4;
+  if ((p.th + 2) * 8 > 96 || p.th * (p.tw / 4) * 2 > 160) return -4;  // halo / dY unit budgets of the producer threads
   if (dt == D3_BF16) {
     if (np == 1) return d3_wgrad_launch_t<1, D3_BF16>(p, s);
     if (np == 2) return d3_wgrad_launch_t<2, D3_BF16>(p, s);

@@ -160,6 +160,7 @@ struct rln_ctx {
   int loss_mode = 0;      // 0: weighted CE (rln_loss), 1: entropy with gradient reversal (rln_entropy_loss)
   float loss_lamda = 0.f;
   const float* last_scales = nullptr;
+  const float* gext = nullptr;  // loss_mode 2: caller-supplied gradient of the probabilities
   // dense-layer arithmetic (rln_set_dense_arith): 0 parts = exact fp32 MFMA kernels, else split 16-bit MFMA (dense3.h)
   int d3_fwd_np = 0, d3_fwd_dt = 0, d3_bwd_np = 0, d3_bwd_dt = 0;
   std::vector<D3PackDesc> d3_desc_f, d3_desc_b;  // host copies, one entry per dense op
@@ -1695,6 +1696,17 @@ int rln_entropy_loss(rln_ctx* c, const float* probs, int n, int h, int w, float 
   return 0;
 }
 
+int rln_set_output_grad(rln_ctx* c, const float* dprobs, int n, int h, int w) {
+  if (!dprobs) return fail(RLN_ERR_ARG, "null gradient");
+  if (n != c->N || h != c->H || w != c->W || !c->with_bwd)
+    return fail(RLN_ERR_WORKSPACE, "backward workspace not set for geometry %dx%dx%d", n, h, w);
+  if (!c->have_train_fwd) return fail(RLN_ERR_STATE, "rln_set_output_grad needs a training rln_forward first");
+  c->gext = dprobs;
+  c->loss_mode = 2;
+  c->have_loss = 1;
+  return 0;
+}
+
 int rln_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t count, float lr, float momentum,
                  float weight_decay, int first_step, float grad_scale, void* stream) {
   if (!params || !grads || !momentum_buf || count < 0) return fail(RLN_ERR_ARG, "bad argument");
@@ -1736,6 +1748,7 @@ int rln_backward(rln_ctx* c, float loss_scale, int seg_begin, int seg_end, void*
     if (e != hipSuccess) return fail((int)e, "memset failed");
     HeadBwdParams q;
     q.mode = c->loss_mode;
+    q.gext = c->gext;
     q.lamda = c->loss_lamda;
     q.inv_count = (float)(1.0 / ((double)N * c->H * c->W));
     q.feat_sign = c->loss_mode == 1 ? -1.f : 1.f;  // grad_reverse between features and classifier (MME)

@@ -93,7 +93,8 @@ int sgd_nesterov(float* p, const float* g, float* buf, long long count, float lr
                  int first_step, float grad_scale, hipStream_t s);
 
 struct HeadBwdParams {
-  int mode;        // 0: class-weighted CE on probabilities, 1: entropy (adentropy)
+  int mode;        // 0: class-weighted CE on probabilities, 1: entropy (adentropy), 2: external d(loss)/d(probs) in gext
+  const float* gext;  // mode 2: [N][ncls][HW]
   float lamda;     // entropy weight
   float inv_count; // 1 / (N*H*W)
   float feat_sign; // -1 when a gradient-reversal layer sits between features and classifier

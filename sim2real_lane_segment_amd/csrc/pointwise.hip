@@ -685,6 +685,12 @@ __global__ __launch_bounds__(256) void head_bwd_data_k(const HeadBwdParams q) {
         gp[k] = (k < p.ncls) ? coef * (qq[k] - ((k == (int)lab) ? 1.f : 0.f)) : 0.f;
         dot = fmaf(pr[k], gp[k], dot);
       }
+    } else if (q.mode == 2) {  // caller-supplied d(loss)/d(probabilities): differentiable module forward
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        gp[k] = (k < p.ncls) ? q.loss_scale * q.gext[((long long)n * p.ncls + k) * p.HW + px] : 0.f;
+        dot = fmaf(pr[k], gp[k], dot);
+      }
     } else {  // d/dp of lamda * mean(sum_k p*log(p+1e-5))
       const float coef = q.loss_scale * q.lamda * q.inv_count;
 #pragma unroll
@@ -863,6 +869,12 @@ __global__ __launch_bounds__(256) void head_bwd_fused_k(const HeadBwdParams q, f
 #pragma unroll
       for (int k = 0; k < NC; ++k) {
         gp[k] = (k < p.ncls) ? coef * (qq[k] - ((k == (int)lab) ? 1.f : 0.f)) : 0.f;
+        dot = fmaf(pr[k], gp[k], dot);
+      }
+    } else if (q.mode == 2) {  // caller-supplied d(loss)/d(probabilities): differentiable module forward
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        gp[k] = (k < p.ncls) ? q.loss_scale * q.gext[((long long)n * p.ncls + k) * p.HW + pxs] : 0.f;
         dot = fmaf(pr[k], gp[k], dot);
       }
     } else {  // d/dp of lamda * mean(sum_k p*log(p+1e-5))

@@ -118,6 +118,7 @@ class Engine:
         self._ws_key = None
         self._keep = []
         self.step_seed = 0
+        self.fwd_token = 0
         self.dense_arith = (0, "bf16", 0, "bf16")
         self.allocate(device)
         arith = DEFAULT_DENSE_ARITH if dense_arith is None else dense_arith
@@ -224,6 +225,7 @@ class Engine:
         _lib.check(self.L.rln_forward(self.ctx, _ptr(x), n, h, w, int(training), _ptr(drop_scales), int(seed),
                                       _ptr(probs), _ptr(feat), int(use_softmax), _stream()), "rln_forward")
         self._keep = [x, drop_scales]  # the backward pass re-reads the input
+        self.fwd_token += 1            # a backward belongs to exactly one forward (see TrainStepFn / ForwardFn)
         return probs, feat
 
     def pack_drop_scales(self, scales: Sequence[torch.Tensor]) -> torch.Tensor:
@@ -251,6 +253,15 @@ class Engine:
         _lib.check(self.L.rln_entropy_loss(self.ctx, _ptr(probs), n, h, w, float(lamda), _ptr(out), _stream()),
                    "rln_entropy_loss")
         return out
+
+    def set_output_grad(self, dprobs: torch.Tensor):
+        """d(loss)/d(probabilities) of the last training forward; a following backward() differentiates through the
+        whole net (rln_set_output_grad)."""
+        self._require_gpu()
+        dprobs = dprobs.to(device=self.device, dtype=torch.float32).contiguous()
+        n, k, h, w = dprobs.shape
+        _lib.check(self.L.rln_set_output_grad(self.ctx, _ptr(dprobs), n, h, w), "rln_set_output_grad")
+        self._keep.append(dprobs)
 
     def sgd_step(self, momentum_buf, lo, hi, lr, momentum, weight_decay, first_step, grads_ptr=None, grad_scale=1.0):
         """Nesterov SGD on the arena range [lo, hi) (one parameter group)."""

@@ -4,17 +4,17 @@ API mirror of rightLaneNetwork/models/FCDenseNet/tiramisu.py: same classes, cons
 arguments, factory functions and state_dict keys (tiramisu.py:7-18,21-125,128-194).  The modules
 hold parameters; ``forward`` hands the whole network to librln.so (see ../../engine.py).
 
-Autograd boundary of this round: the fused training step (``TrainingBase`` /
-``SimpleTrainModule.training_step``) is differentiable end to end inside the HIP library;
-``forward`` of the pieces below is inference / evaluation only and returns tensors without a
-grad_fn (a differentiable stand-alone feature extractor is the MME row of SURVEY.md §8f).
+Autograd boundary: the fused training steps and the fused ``forward`` of ``FCDenseNet`` / ``TrainingBase`` (train mode,
+autograd enabled) are differentiable end to end inside the HIP library; ``forward`` of the stand-alone pieces
+(``FCDenseNetFeatureExtractor``, ``FCDenseNetClassifier``) is inference / evaluation only and raises when it is asked
+for gradients.
 """
 import torch
 import torch.nn as nn
 from torch.autograd import Function
 
 from ...engine import classifier_op
-from ...owner import EngineOwner
+from ...owner import EngineOwner, ForwardFn
 from .layers import Bottleneck, DenseBlock, TransitionDown, TransitionUp  # noqa: F401  (re-exported like the reference)
 from .layers import DenseLayer, center_crop  # noqa: F401
 
@@ -91,16 +91,22 @@ class FCDenseNetFeatureExtractor(nn.Module, EngineOwner):
         return self.featureChannels
 
     def forward(self, x):
+        """Stand-alone feature extractor: inference / evaluation only.  Differentiable use goes through the owning
+        module (``TrainingBase.forward`` / ``FCDenseNet.forward`` / the fused training steps): composing
+        ``featureExtractor -> grad_reverse -> classifier`` by hand (MMETrainingModule.py:28-33) is what
+        ``MMETrainingModule.training_step`` runs fused; asking THIS call for gradients raises instead of silently
+        returning a tensor without grad_fn."""
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError(
+                "FCDenseNetFeatureExtractor.forward is inference-only on the HIP path: call it under torch.no_grad() / "
+                "in eval mode, or differentiate through the owning module (TrainingBase.forward, FCDenseNet.forward, "
+                "SimpleTrainModule / MMETrainingModule.training_step)")
         parent = self.__dict__.get("_rln_parent")
         owner = parent if parent is not None else self
         eng = owner._rln_sync()
         with torch.no_grad():
             _, feat = eng.forward(x, training=self.training, with_backward=False, want_probs=False, want_feat=True)
         return feat
-
-
-class _StandaloneFeatureOwner:
-    pass
 
 
 class FCDenseNetClassifier(nn.Module):
@@ -117,6 +123,11 @@ class FCDenseNetClassifier(nn.Module):
         if tuple(self.finalConv.kernel_size) != (1, 1):
             raise RuntimeError("only the kernel_size=1 classifier (what every reference script builds) runs on the "
                                "HIP path")
+        if torch.is_grad_enabled() and (x.requires_grad or (self.training and self.finalConv.weight.requires_grad)):
+            raise RuntimeError(
+                "FCDenseNetClassifier.forward is inference-only on the HIP path: call it under torch.no_grad() / in eval "
+                "mode, or differentiate through the owning module (TrainingBase.forward, FCDenseNet.forward, the fused "
+                "training steps)")
         with torch.no_grad():
             return classifier_op(x, self.finalConv.weight, self.finalConv.bias, self.T, use_softmax=useSoftmax)
 
@@ -140,6 +151,8 @@ class FCDenseNet(nn.Module, EngineOwner):
         return out
 
     def forward(self, x):
+        if self.training and torch.is_grad_enabled():  # differentiable (comparison.py-style user training code)
+            return ForwardFn.apply(self, x, None, None, *self._rln_params_in_arena_order())
         eng = self._rln_sync()
         with torch.no_grad():
             probs, _ = eng.forward(x, training=self.training, with_backward=False)

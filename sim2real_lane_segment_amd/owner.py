@@ -119,6 +119,7 @@ class TrainStepFn(torch.autograd.Function):
             out, _, _ = eng.loss(probs, y, weighted=True)
         ctx.owner = owner
         ctx.n_params = len(params)
+        ctx.token = eng.fwd_token
         loss = out[0].clone()
         extra = out.detach()
         ctx.mark_non_differentiable(extra, probs)
@@ -128,6 +129,7 @@ class TrainStepFn(torch.autograd.Function):
     def backward(ctx, g_loss, g_extra, g_probs):
         owner = ctx.owner
         eng = owner._rln_engine
+        _check_token(eng, ctx.token)
         eng.backward(1.0)
         # hand autograd a private flat copy (AccumulateGrad may keep or add into these tensors), scaled by the
         # incoming d(loss); FusedAdamW recognises the flat layout and consumes it with one kernel.
@@ -137,6 +139,47 @@ class TrainStepFn(torch.autograd.Function):
             if m.kind == _lib.T_PARAM and m.name in owner._rln_param_set:
                 grads.append(flat[m.offset:m.offset + m.numel].view(m.shape))
         return (None, None, None, None, None) + tuple(grads)
+
+
+def _check_token(eng, token):
+    """The engine keeps the activations of its LAST forward only: a backward of an older forward would silently use the
+    wrong ones, so it fails loudly instead."""
+    if eng.fwd_token != token:
+        raise RuntimeError("backward of a stale forward: the engine keeps the activations of the most recent forward "
+                           "only (another forward ran in between); run backward before the next forward, or use "
+                           "separate modules")
+
+
+def _flat_param_grads(owner, eng, scale=None):
+    flat = eng.grads * scale if scale is not None else eng.grads.clone()
+    grads = []
+    for m in eng.metas:
+        if m.kind == _lib.T_PARAM and m.name in owner._rln_param_set:
+            grads.append(flat[m.offset:m.offset + m.numel].view(m.shape))
+    return tuple(grads)
+
+
+class ForwardFn(torch.autograd.Function):
+    """Differentiable ``forward`` of the fused net (train mode): probabilities out, d(loss)/d(probabilities) in
+    (TrainingBase.forward used inside user-written steps: SimpleTrain.py:15, MMETrainingModule.py:34-35).  The gradient
+    with respect to the input image is not produced (the reference's data loaders never ask for it)."""
+
+    @staticmethod
+    def forward(ctx, owner, x, drop_scales, seed, *params):
+        eng = owner._rln_sync()
+        probs, _ = eng.forward(x, training=True, with_backward=True, drop_scales=drop_scales, seed=seed)
+        ctx.owner = owner
+        ctx.token = eng.fwd_token
+        return probs
+
+    @staticmethod
+    def backward(ctx, g_probs):
+        owner = ctx.owner
+        eng = owner._rln_engine
+        _check_token(eng, ctx.token)
+        eng.set_output_grad(g_probs)
+        eng.backward(1.0)
+        return (None, None, None, None) + _flat_param_grads(owner, eng)
 
 
 class FusedAdamW(torch.optim.Optimizer):

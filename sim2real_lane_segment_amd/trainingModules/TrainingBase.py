@@ -11,7 +11,7 @@ import torch
 from .._lightning import LightningModule
 from ..metrics import accuracy_from_confusion, dice_from_confusion, iou_from_confusion
 from ..models.FCDenseNet.tiramisu import FCDenseNet67Base, FCDenseNet67Classifier
-from ..owner import EngineOwner
+from ..owner import EngineOwner, ForwardFn
 
 
 def getClassWeight(targets, maxClasses: int = None):
@@ -59,7 +59,12 @@ class TrainingBase(LightningModule, EngineOwner):
         return parser
 
     def forward(self, x):
-        """featureExtractor -> classifier as one fused HIP forward (TrainingBase.py:54-57)."""
+        """featureExtractor -> classifier as one fused HIP forward (TrainingBase.py:54-57).  In train mode with autograd
+        enabled the result carries a grad_fn (HIP backward through the whole net), so a user-written step such as
+        ``cross_entropy(self.forward(x), y).backward()`` (SimpleTrain.py:15-16) trains the parameters; in eval mode or
+        under ``torch.no_grad()`` it is the plain inference forward."""
+        if self.training and torch.is_grad_enabled():
+            return ForwardFn.apply(self, x, None, None, *self._rln_params_in_arena_order())
         eng = self._rln_sync()
         with torch.no_grad():
             probs, _ = eng.forward(x, training=self.training, with_backward=False)

@@ -46,3 +46,27 @@ def cfg_from_arrays(z, cfg_cls):
     return cfg_cls(in_channels=misc[0], down_blocks=tuple(int(v) for v in z["cfg_down"]),
                    up_blocks=tuple(int(v) for v in z["cfg_up"]), bottleneck_layers=misc[1],
                    growth_rate=misc[2], out_chans_first_conv=misc[3], n_classes=misc[4])
+
+
+def det_state(shapes, seed):
+    """Deterministic weights for nets too large to store in a fixture (EncDecNet(64,3,7): 7.2 M parameters): generated
+    identically by gen_golden.py (loaded into the reference class, strict=True) and by the tests.  Keys in sorted order;
+    conv weights ~ N(0, 1/fan_in), biases small, BatchNorm affine / running statistics away from (1, 0, 0, 1)."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for name in sorted(shapes):
+        shp = tuple(shapes[name])
+        if name.endswith("num_batches_tracked"):
+            out[name] = torch.zeros(shp, dtype=torch.int64)
+        elif name.endswith("running_var"):
+            out[name] = 0.75 + 0.5 * torch.rand(shp, generator=g)
+        elif name.endswith("running_mean"):
+            out[name] = 0.1 * (torch.rand(shp, generator=g) - 0.5)
+        elif len(shp) == 4:
+            fan_in = shp[1] * shp[2] * shp[3]
+            out[name] = torch.randn(shp, generator=g) / fan_in ** 0.5
+        elif ".bn." in name and name.endswith("weight"):
+            out[name] = 0.75 + 0.5 * torch.rand(shp, generator=g)
+        else:
+            out[name] = 0.2 * (torch.rand(shp, generator=g) - 0.5)
+    return out

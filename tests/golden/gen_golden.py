@@ -333,6 +333,31 @@ def gen_encdec(name, n_feat, n_levels, k, n_lin, n, h, w, seed):
     print(name, "ok", out["eval_out"].shape)
 
 
+def gen_encdec_refsize(name, k, seed):
+    """EncDecNet at the sizes the reference itself builds (models/EncDecNet.py:119-130: EncDecNet(64, 3, 7) on
+    ones(1, 3, 120, 160); (64, 3, 3) is the survey's second size): eval forward of the reference class with the
+    deterministic weights of tests/golden/common.py:det_state on the script's all-ones input and on a seeded frame."""
+    from models.EncDecNet import EncDecNet
+    from tests.golden.common import det_state
+    net = EncDecNet(64, 3, k)
+    assert net.getNParams() == (7237570 if k == 7 else 1331650)
+    net.load_state_dict(det_state({key: v.shape for key, v in net.state_dict().items()}, seed), strict=True)
+    net.eval()
+    x, _ = synth_batch(1, 120, 160, 2, seed + 2)
+    out = dict(k=k, seed=seed)
+    with torch.no_grad():
+        for tag, inp in (("ones", torch.ones(1, 3, 120, 160)), ("rand", x)):
+            y = net(inp)
+            assert y.shape == (1, 2, 120, 160)
+            idx = sample_idx(y.numel(), 4096, 77)
+            out[tag + "_samp"] = y.reshape(-1)[idx].numpy()
+            out[tag + "_mask"] = pack_masks(y.argmax(1), 2)
+            out[tag + "_gapmin"] = float((y[:, 0] - y[:, 1]).abs().min())
+            out[tag + "_near"] = torch.nonzero(((y[:, 0] - y[:, 1]).abs() < 1e-4).reshape(-1)).reshape(-1).numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "ok", out["rand_gapmin"], len(out["rand_near"]))
+
+
 def gen_misc(name):
     """Third-party arithmetic at the reference's call sites: AdamW(lr,weight_decay) 3 steps,
     CosineAnnealingLR(25, eta_min=lr/lrRatio) table, getClassWeight incl. an absent class."""
@@ -381,6 +406,9 @@ def main():
         gen_encdec("encdec_k3_relu_24x40", 8, 2, 3, "relu", 2, 24, 40, 900)
         gen_encdec("encdec_k7_leaky_40x56", 8, 3, 7, "leakyRelu", 2, 40, 56, 910)
         gen_encdec("encdec_k3_prelu_30x34", 6, 2, 3, "prelu", 1, 30, 34, 920)
+    if "encdec_ref" in which:
+        gen_encdec_refsize("encdec_ref_64_3_3_120x160", 3, 930)
+        gen_encdec_refsize("encdec_ref_64_3_7_120x160", 7, 940)
     if "mme" in which:
         gen_mme("mme_tiny_40x56", tiny, 2, 40, 56, 800)
     if "tiny" in which:

@@ -85,3 +85,54 @@ def test_hip_forward_vs_reference(name):
     # device-generated masks: runs, output is a distribution over the 2 classes
     out_r = net(x.cuda())
     assert torch.allclose(out_r.sum(1), torch.ones_like(out_r[:, 0]), atol=1e-5)
+
+
+# ---- the sizes the reference itself builds (models/EncDecNet.py:119-130) ---------------------------------
+REF_CASES = [("encdec_ref_64_3_3_120x160", 3), ("encdec_ref_64_3_7_120x160", 7)]
+
+
+def _ref_inputs(z):
+    from tests.golden.common import synth_batch
+    x, _ = synth_batch(1, 120, 160, 2, int(z["seed"]) + 2)
+    return {"ones": torch.ones(1, 3, 120, 160), "rand": x}
+
+
+def _check_ref_output(z, tag, y, atol):
+    from tests.golden.common import sample_idx, unpack_masks
+    idx = sample_idx(y.numel(), 4096, 77)
+    np.testing.assert_allclose(y.reshape(-1)[idx].numpy(), z[tag + "_samp"], atol=atol)
+    mask = y.argmax(1).reshape(-1)
+    ref = unpack_masks(z[tag + "_mask"], mask.numel())
+    near = set(int(i) for i in z[tag + "_near"])  # pixels whose two class probabilities differ by < 1e-4
+    diff = torch.nonzero(mask != ref).reshape(-1).tolist()
+    assert all(d in near for d in diff), f"{len(diff)} argmax flips, some outside the near-tie list"
+    return len(diff)
+
+
+@pytest.mark.parametrize("name,k", REF_CASES)
+def test_oracle_vs_reference_at_reference_size(name, k):
+    from tests.golden.common import det_state
+    from sim2real_lane_segment_amd.models.EncDecNet import EncDecNet
+    z = load(name)
+    net = EncDecNet(64, 3, k)  # parameter container only (CPU): shapes for the deterministic weights
+    assert net.getNParams() == (7237570 if k == 7 else 1331650)
+    st = det_state({key: v.shape for key, v in net.state_dict().items()}, int(z["seed"]))
+    with torch.no_grad():
+        for tag, x in _ref_inputs(z).items():
+            _check_ref_output(z, tag, E.forward(st, x, 3, k, "relu"), 5e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,k", REF_CASES)
+def test_hip_forward_at_reference_size(name, k):
+    from tests.golden.common import det_state
+    from sim2real_lane_segment_amd.models.EncDecNet import EncDecNet
+    z = load(name)
+    net = EncDecNet(64, 3, k)
+    net.load_state_dict(det_state({key: v.shape for key, v in net.state_dict().items()}, int(z["seed"])))
+    net = net.cuda().eval()
+    for tag, x in _ref_inputs(z).items():
+        out = net(x.cuda())
+        assert out.shape == (1, 2, 120, 160)
+        flips = _check_ref_output(z, tag, out.cpu(), 1e-4)
+        print(f"[{name}/{tag}] argmax flips vs the reference: {flips}")
