@@ -26,23 +26,29 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_16BIT_MFMA_TFLOPS = 2500.0  # dense bf16 / f16 MFMA peak (same guide; not the 2:1-sparsity figure)
 PEAK_HBM_GBS = 8000.0
 TRAIN_FLOPS_PER_IMAGE = 47_718_689_280  # 3 x 15,906,229,760
+PMC_SUMMARY = "r02_pmc_traffic.json"     # profiles/: FETCH_SIZE / WRITE_SIZE passes of this same command
 
-
-# kernel-name prefixes of each profiled class in the rocprofv3 --pmc summary (profiles/r01_pmc_traffic.json)
+# kernel-name prefixes of each profiled class in the rocprofv3 --pmc summary
 CLASS_KERNELS = {
+    "dense3_fwd": ("void rln::d3_fwd_k<",),
+    "dense3_wgrad": ("void rln::d3_wgrad_k<",),
+    "dense3_dgrad_pull": ("void rln::d3_pull_k<",),
     "dense_conv3x3_fwd": ("void rln::igemm_k<3, 1, 1, 0,",),
     "dense_conv3x3_dgrad": ("void rln::dgrad_loop_k<",),
     "dense_conv3x3_wgrad": ("void rln::wgrad_dense_q_k<", "void rln::wgrad_k<3, 1, 1,"),
 }
+# classes that run on the 16-bit MFMA pipe with split operands: products issued per algorithmic multiply-add
+SPLIT_CLASSES = ("dense3_fwd", "dense3_wgrad", "dense3_dgrad_pull")
 
 
 def pmc_traffic(class_name):
     """HBM bytes per launch of a kernel class from the committed PMC pass (FETCH_SIZE/WRITE_SIZE collected in their
     own rocprofv3 --pmc runs of this same command and corrected as tools/pmc_traffic.py documents); None if the
     summary or the class mapping is absent.  Not collected live: counters need the profiler around the process."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", PMC_SUMMARY)
     pref = CLASS_KERNELS.get(class_name)
     if pref is None or not os.path.exists(path):
         return None
@@ -328,13 +334,16 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32",  # storage and accumulation; the dense 3x3 MFMAs take split 16-bit operands (config.dense_arith)
             "data": "synthetic",
             "config": {"workload": f"FCDenseNet67 num_cls=4 SimpleTrainModule training step (fwd+weighted CE+bwd+AdamW), "
                                    f"per-GPU batch {B}, 3x{args.height}x{args.width} synthetic Duckietown frames, "
                                    f"random-init weights, Dropout2d+BatchNorm in train mode",
                        "global_batch": world * B, "parallelism": f"dp{world}", "final_loss": round(loss, 5),
-                       "api": args.api},
+                       "api": args.api,
+                       "dense_arith": "fwd %sx%d / bwd %sx%d split-operand MFMA (0 parts = exact fp32 MFMA), fp32 storage "
+                                      "and accumulation" % (eng.dense_arith[1], eng.dense_arith[0], eng.dense_arith[3],
+                                                            eng.dense_arith[2])},
         }
         if module_api is not None:
             result["module_api"] = module_api
@@ -342,23 +351,31 @@ def main():
             timed = [p for p in prof if p["launches"] > 0]
             total_ms = sum(p["ms"] for p in timed)
             dom = max((p for p in timed if p["flops"] > 0), key=lambda p: p["ms"])
-            tfl = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-            gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
-            # the binding roof of a class is the one its algorithmic work sits closer to
-            if tfl / PEAK_F32_MFMA_TFLOPS >= gbs / PEAK_HBM_GBS:
-                roof = {"bound": "mfma", "achieved": round(tfl, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(tfl / PEAK_F32_MFMA_TFLOPS, 4)}
+            fwd_parts, _, bwd_parts, _ = eng.dense_arith
+            parts = fwd_parts if dom["name"] == "dense3_fwd" else bwd_parts
+            products = {1: 1, 2: 3, 3: 6}.get(parts, 1) if dom["name"] in SPLIT_CLASSES else 1
+            mfma_peak = PEAK_16BIT_MFMA_TFLOPS if dom["name"] in SPLIT_CLASSES else PEAK_F32_MFMA_TFLOPS
+            tfl = dom["flops"] / (dom["ms"] * 1e-3) / 1e12          # algorithmic flops (2 per multiply-add)
+            gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9           # algorithmic bytes
+            mfma_frac = tfl * products / mfma_peak                  # matrix-pipe work incl. the split products
+            hbm_frac = gbs / PEAK_HBM_GBS
+            # the binding roof of a class is the one its work sits closer to
+            if mfma_frac >= hbm_frac:
+                roof = {"bound": "mfma", "achieved": round(tfl * products, 3), "peak": mfma_peak, "unit": "TFLOP/s",
+                        "frac": round(mfma_frac, 4)}
             else:
                 roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": round(gbs / PEAK_HBM_GBS, 4)}
+                        "frac": round(hbm_frac, 4)}
             roof.update({
                 "kernel": dom["name"], "traffic": pmc_traffic(dom["name"]),
-                "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc pass, profiles/r01_pmc_traffic.json)",
+                "traffic_unit": f"HBM bytes per launch (rocprofv3 --pmc pass, profiles/{PMC_SUMMARY})",
                 "alg_bytes_per_launch": round(dom["bytes"] / dom["launches"]), "launches": dom["launches"],
                 "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
                 "share_of_kernel_time": round(dom["ms"] / total_ms, 4),
                 "instrumented_ms_per_step": round(instrumented_ms, 3),
                 "alg_tflops": round(tfl, 3), "alg_GBps": round(gbs, 1),
+                "mfma_products_per_mac": products, "frac_of_mfma_peak": round(mfma_frac, 4),
+                "frac_of_hbm_peak": round(hbm_frac, 4),
                 "whole_step_tflops": round(TRAIN_FLOPS_PER_IMAGE * images / elapsed / 1e12, 3)
                 if (args.height, args.width) == (120, 160) else None,
                 "whole_step_frac_of_f32_mfma_peak": round(TRAIN_FLOPS_PER_IMAGE * images / elapsed / 1e12

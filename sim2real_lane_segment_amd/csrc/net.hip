@@ -84,13 +84,14 @@ struct Level {
 
 enum ProfClass {
   PC_DENSE_FWD = 0, PC_FIRST_FWD, PC_TD_FWD, PC_TU_FWD, PC_DENSE_DGRAD, PC_TD_DGRAD, PC_TU_DGRAD, PC_DENSE_WGRAD,
-  PC_FIRST_WGRAD, PC_TD_WGRAD, PC_TU_WGRAD, PC_BN, PC_GRADFIN, PC_REDUCE, PC_HEAD_FWD, PC_LOSS, PC_HEAD_BWD, PC_COUNT
+  PC_FIRST_WGRAD, PC_TD_WGRAD, PC_TU_WGRAD, PC_BN, PC_GRADFIN, PC_REDUCE, PC_HEAD_FWD, PC_LOSS, PC_HEAD_BWD,
+  PC_D3_FWD, PC_D3_PULL, PC_D3_WGRAD, PC_COUNT
 };
 static const char* kProfNames[PC_COUNT] = {
     "dense_conv3x3_fwd", "first_conv_fwd", "transition_down_fwd", "transition_up_fwd", "dense_conv3x3_dgrad",
     "transition_down_dgrad", "transition_up_dgrad", "dense_conv3x3_wgrad", "first_conv_wgrad",
     "transition_down_wgrad", "transition_up_wgrad", "bn_stats_affine", "grad_finalize", "partial_reduce",
-    "head_fwd", "loss", "head_bwd"};
+    "head_fwd", "loss", "head_bwd", "dense3_fwd", "dense3_dgrad_pull", "dense3_wgrad"};
 struct ProfEntry {
   hipEvent_t a, b;
   int cls;
@@ -843,7 +844,7 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
       {
         const double flops = 2.0 * o.cin * o.cout * 9.0 * q.H * q.W * N;
         const double bytes = 4.0 * N * ((double)o.cin + o.cout) * q.H * q.W;
-        ProfScope ps(c, PC_DENSE_FWD, flops, bytes, s);
+        ProfScope ps(c, PC_D3_FWD, flops, bytes, s);
         RLN_TRY(d3_fwd_launch(q, N, c->d3_fwd_np, c->d3_fwd_dt, s));
       }
       if (training)
@@ -1388,7 +1389,7 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
         {
           const double wflops = 2.0 * o.cout * o.cin * 9.0 * plane * N;
           const double wbytes = 4.0 * N * ((double)o.cout + o.cin) * plane;
-          ProfScope ps(c, PC_DENSE_WGRAD, wflops, wbytes, s);
+          ProfScope ps(c, PC_D3_WGRAD, wflops, wbytes, s);
           RLN_TRY(d3_wgrad_launch(g, c->d3_bwd_np, c->d3_bwd_dt, s));
         }
         ProfScope ps2(c, PC_REDUCE, 0, 4.0 * (g.nranges + 1) * w.wsize, s);
@@ -1483,7 +1484,7 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
       double flops = 0.0;
       for (int i = 0; i < nl; ++i) flops += 2.0 * C0 * first.cout * 9.0 * plane * N;
       const double bytes = 4.0 * N * plane * ((double)nl * first.cout + 2.0 * C0 + (double)(q.acc_hi - q.acc_lo));
-      ProfScope ps(c, PC_DENSE_DGRAD, flops, bytes, s);
+      ProfScope ps(c, PC_D3_PULL, flops, bytes, s);
       RLN_TRY(d3_pull_launch(q, c->d3_bwd_np, c->d3_bwd_dt, s));
     }
     f.nl = nl;
