@@ -188,6 +188,11 @@ def main():
                     help="engine: TrainStepper (direct C-ABI calls, overlapped all-reduce); module: the reference-shaped "
                          "path training_step -> loss.backward() -> optimizer.step() (what Lightning drives)")
     ap.add_argument("--no-module-api", action="store_true", help="skip the secondary module-API timing")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    help="f32 (default): fp32-parity arithmetic (split 16-bit MFMA operands, DESIGN.md 4.1); bf16: plain "
+                         "one-part bf16 MFMA operands in the dense 3x3 kernels (storage and accumulation stay fp32) -- the "
+                         "throughput mode of BASELINE.json configs[1]; its mask agreement is measured in "
+                         "tests/test_gpu_dense3.py")
     ap.add_argument("--fwd-arith", default=None, help="dense 3x3 forward arithmetic: fp32 | bf16x1..3 | f16x1..2")
     ap.add_argument("--bwd-arith", default=None, help="dense 3x3 backward arithmetic: fp32 | bf16x1..3 | f16x1..2")
     args = ap.parse_args()
@@ -227,6 +232,8 @@ def main():
     model = SimpleTrainModule(lr=1e-3, lrRatio=1e3, decay=1e-4, num_cls=4).to(dev)  # random init, FCDenseNet67
     model.train()
     eng = model._rln_sync()
+    if args.dtype == "bf16" and not (args.fwd_arith or args.bwd_arith):
+        args.fwd_arith = args.bwd_arith = "bf16x1"
     if args.fwd_arith or args.bwd_arith:
         def parse(a):
             if a in (None, "fp32"):
@@ -334,7 +341,9 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",  # storage and accumulation; the dense 3x3 MFMAs take split 16-bit operands (config.dense_arith)
+            # storage and accumulation are fp32 in both modes; "f32" = split 16-bit MFMA operands at fp32-parity error,
+            # "bf16" = plain bf16 MFMA operands in the dense 3x3 kernels (config.dense_arith names the exact setting)
+            "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": f"FCDenseNet67 num_cls=4 SimpleTrainModule training step (fwd+weighted CE+bwd+AdamW), "
                                    f"per-GPU batch {B}, 3x{args.height}x{args.width} synthetic Duckietown frames, "
