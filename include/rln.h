@@ -172,6 +172,13 @@ int rln_op_dense3_fwd(const float* x, int n, int cin, int x_ctot, int x_coff, in
                       const float* b, const float* weight, const float* bias, int cout, const float* scale, float* out,
                       int out_ctot, int out_coff, float* stats, int parts, int dtype, void* workspace,
                       size_t workspace_bytes, void* stream);
+/* rln_op_td_fwd: the TransitionDown forward (layers.py:45-58: BN -> ReLU -> Conv2d 1x1 -> Dropout2d scale -> MaxPool2d(2))
+ * on the 16-bit MFMA pipe with split fp32 operands (csrc/pw1.h); arguments as rln_op_conv_bnrelu with ksize 1, pool 1,
+ * plus parts / dtype as rln_op_dense3_fwd.  Needs an even W and 8-byte aligned views. */
+int rln_op_td_fwd(const float* x, int n, int cin, int x_ctot, int x_coff, int h, int w, const float* a, const float* b,
+                  const float* weight, const float* bias, int cout, const float* scale, float* out, int out_ctot,
+                  int out_coff, uint8_t* pool_idx, float* stats, int parts, int dtype, void* workspace,
+                  size_t workspace_bytes, void* stream);
 /* rln_op_convt: ConvTranspose2d(k3,s2,p0)+bias cropped top-left to (hout,wout) (layers.py:58-67,82-86). */
 int rln_op_convt(const float* x, int n, int cin, int h, int w, const float* weight, const float* bias, int cout,
                  float* out, int out_ctot, int out_coff, int hout, int wout, void* stream);

@@ -1,81 +1,12 @@
 // Dense-block 3x3 kernels on the 16-bit MFMA pipe with split fp32 operands (see dense3.h).
 #include "dense3.h"
+#include "split16.h"
 
 #include <algorithm>
 #include <cstdio>
 #include <type_traits>
 
 namespace rln {
-
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// ---- operand splitting: x = part0 + part1 (+ part2), every part the 16-bit rounding of the remainder -------------
-template <int DT>
-__device__ __forceinline__ unsigned pack2(f32x2 v) {
-  if constexpr (DT == D3_BF16) {
-    union { bf16x2 h; unsigned u; } c;
-    c.h = __builtin_convertvector(v, bf16x2);
-    return c.u;
-  } else {
-    union { f16x2 h; unsigned u; } c;
-    c.h = __builtin_convertvector(v, f16x2);
-    return c.u;
-  }
-}
-template <int DT>
-__device__ __forceinline__ f32x2 unpack2(unsigned u) {
-  if constexpr (DT == D3_BF16) {
-    union { bf16x2 h; unsigned u; } c;
-    c.u = u;
-    return __builtin_convertvector(c.h, f32x2);
-  } else {
-    union { f16x2 h; unsigned u; } c;
-    c.u = u;
-    return __builtin_convertvector(c.h, f32x2);
-  }
-}
-template <int DT, int NP>
-__device__ __forceinline__ void split2(float x0, float x1, unsigned (&out)[NP]) {
-  f32x2 r = {x0, x1};
-#pragma unroll
-  for (int p = 0; p < NP; ++p) {
-    out[p] = pack2<DT>(r);
-    if (p + 1 < NP) r = r - unpack2<DT>(out[p]);
-  }
-}
-
-template <int DT>
-__device__ __forceinline__ f32x4 mfma32(const uint4& a, const uint4& b, f32x4 c) {
-  if constexpr (DT == D3_BF16) {
-    union { uint4 u; bf16x8 v; } ca, cb;
-    ca.u = a;
-    cb.u = b;
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca.v, cb.v, c, 0, 0, 0);
-  } else {
-    union { uint4 u; f16x8 v; } ca, cb;
-    ca.u = a;
-    cb.u = b;
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(ca.v, cb.v, c, 0, 0, 0);
-  }
-}
-// acc += sum of the leading cross terms of (a0+a1+a2)*(b0+b1+b2), smallest terms first
-template <int DT, int NP>
-__device__ __forceinline__ f32x4 mfma_split(const uint4 (&a)[NP], const uint4 (&b)[NP], f32x4 c) {
-  if constexpr (NP == 3) {
-    c = mfma32<DT>(a[2], b[0], c);
-    c = mfma32<DT>(a[1], b[1], c);
-    c = mfma32<DT>(a[0], b[2], c);
-  }
-  if constexpr (NP >= 2) {
-    c = mfma32<DT>(a[1], b[0], c);
-    c = mfma32<DT>(a[0], b[1], c);
-  }
-  return mfma32<DT>(a[0], b[0], c);
-}
 
 // =============================================================================================
 // weight packing

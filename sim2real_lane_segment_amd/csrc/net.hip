@@ -21,6 +21,7 @@
 
 #include "../../include/rln.h"
 #include "dense3.h"
+#include "pw1.h"
 #include "igemm.h"
 #include "pointwise.h"
 
@@ -170,6 +171,11 @@ struct rln_ctx {
   D3PackDesc* d3_desc_b_dev = nullptr;
   uint4* d3_packed = nullptr;
   int d3_units_f = 0, d3_units_b = 0;
+  std::vector<P1PackDesc> p1_desc_f, p1_desc_b;  // TransitionDown 1x1 weights (same packed buffer)
+  std::vector<long long> p1_wf_off, p1_wb_off;
+  P1PackDesc* p1_desc_f_dev = nullptr;
+  P1PackDesc* p1_desc_b_dev = nullptr;
+  int p1_units_f = 0, p1_units_b = 0;
   std::vector<float*> dyblk;  // one finalised-output-gradient buffer per layer of a dense block (pull-form backward)
 };
 
@@ -518,6 +524,7 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
       igemm_tile_dims(IG_CONV1_POOL, tile, &th, &tw);
       const size_t blocks = (size_t)n * ((Hs + th - 1) / th) * ((Ws + tw - 1) / tw);
       stat_max = std::max(stat_max, blocks * o.cout * 2);
+      if (c->d3_fwd_np > 0 || c->d3_bwd_np > 0) stat_max = std::max(stat_max, (size_t)256 * std::max(o.cout, o.cin) * 2);
       pool_off[k] = (int64_t)pool_bytes;
       pool_bytes += (size_t)n * o.cout * Hd * Wd;
       pool_bytes = (pool_bytes + 255) & ~(size_t)255;
@@ -595,6 +602,37 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
       dbh.push_back(d);
     }
   }
+  std::vector<P1PackDesc> pfh, pbh;
+  std::vector<long long> p1f_off(c->ops.size(), -1), p1b_off(c->ops.size(), -1);
+  int pu_f = 0, pu_b = 0;
+  for (size_t k = 0; k < c->ops.size(); ++k) {
+    const Op& o = c->ops[k];
+    if (o.type != OP_TD) continue;
+    P1PackDesc d;
+    d.w_off = o.conv.w;
+    d.cin = o.cin;
+    d.cout = o.cout;
+    if (c->d3_fwd_np > 0) {
+      d.wf_off = pk_total;
+      d.wb_off = -1;
+      d.unit_begin = pu_f;
+      d.n_units = p1_units_f(o.cin, o.cout);
+      p1f_off[k] = pk_total;
+      pk_total += (long long)d.n_units * c->d3_fwd_np * 64;
+      pu_f += d.n_units;
+      pfh.push_back(d);
+    }
+    if (c->d3_bwd_np > 0 && with_bwd) {
+      d.wf_off = -1;
+      d.wb_off = pk_total;
+      d.unit_begin = pu_b;
+      d.n_units = p1_units_b(o.cin, o.cout);
+      p1b_off[k] = pk_total;
+      pk_total += (long long)d.n_units * c->d3_bwd_np * 64;
+      pu_b += d.n_units;
+      pbh.push_back(d);
+    }
+  }
   // pull-form data gradient: the dY of every layer of a block stays alive until the block's input channels are done
   int max_block_layers = 0;
   size_t dy_dense_max = 0;
@@ -615,6 +653,8 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
   uint4* d3_packed = cv.take<uint4>((size_t)pk_total);
   D3PackDesc* d3_df = cv.take<D3PackDesc>(dfh.size());
   D3PackDesc* d3_db = cv.take<D3PackDesc>(dbh.size());
+  P1PackDesc* p1_df = cv.take<P1PackDesc>(pfh.size());
+  P1PackDesc* p1_db = cv.take<P1PackDesc>(pbh.size());
   int* lcounts = cv.take<int>(32 + 256);
   float* lpartial = cv.take<float>((size_t)loss_blocks((long long)n * hw0) * 4);
   float* lresult = cv.take<float>(64);
@@ -653,6 +693,14 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
     c->d3_desc_b_dev = d3_db;
     c->d3_units_f = units_f;
     c->d3_units_b = units_b;
+    c->p1_desc_f = pfh;
+    c->p1_desc_b = pbh;
+    c->p1_wf_off = p1f_off;
+    c->p1_wb_off = p1b_off;
+    c->p1_desc_f_dev = p1_df;
+    c->p1_desc_b_dev = p1_db;
+    c->p1_units_f = pu_f;
+    c->p1_units_b = pu_b;
     c->loss.counts = lcounts;
     c->loss.partial = lpartial;
     c->loss.result = lresult;
@@ -850,6 +898,40 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
       if (training)
         RLN_TRY(finalize_stats(c, o.dst_level, o.out_off, o.cout, (long long)N * q.tiles_x * q.tiles_y, s,
                                (long long)k));
+      return 0;
+    }
+  }
+  if (o.type == OP_TD && c->d3_fwd_np > 0 && c->p1_wf_off[k] >= 0) {  // split-operand 16-bit MFMA kernel (pw1.h)
+    const Level& sl = c->levels[o.src_level];
+    P1Fwd q;
+    memset(&q, 0, sizeof(q));
+    q.S = p.in;
+    q.ns = p.in_ns;
+    q.cs = p.in_cs;
+    q.H = sl.H;
+    q.W = sl.W;
+    q.Cin = o.cin;
+    q.N = N;
+    q.pa = p.pa;
+    q.pb = p.pb;
+    q.wpk = c->d3_packed + c->p1_wf_off[k];
+    q.bias = p.bias;
+    q.nscale = p.nscale;
+    q.out = p.out;
+    q.out_ns = p.out_ns;
+    q.out_cs = p.out_cs;
+    q.Cout = o.cout;
+    q.pool_idx = p.pool_idx;
+    q.stat_partial = p.stat_partial;
+    if (p1_fwd_supported(q) && dl.H == sl.H / 2 && dl.W == sl.W / 2) {
+      p1_fwd_plan(&q, c->d3_fwd_np);
+      {
+        const double flops = 2.0 * o.cin * o.cout * sl.H * sl.W * N;
+        const double bytes = 4.0 * N * ((double)o.cin * sl.H * sl.W + 1.25 * o.cout * dl.H * dl.W);
+        ProfScope ps(c, PC_TD_FWD, flops, bytes, s);
+        RLN_TRY(p1_fwd_launch(q, c->d3_fwd_np, c->d3_fwd_dt, s));
+      }
+      if (training) RLN_TRY(finalize_stats(c, o.dst_level, o.out_off, o.cout, (long long)q.bpg, s, (long long)k));
       return 0;
     }
   }
@@ -1610,6 +1692,16 @@ int rln_set_workspace(rln_ctx* c, void* ws, size_t bytes, int n, int h, int w, i
                     hipMemcpyHostToDevice);
     if (e != hipSuccess) return fail((int)e, "descriptor upload failed");
   }
+  if (!c->p1_desc_f.empty() || !c->p1_desc_b.empty()) {
+    hipError_t e = hipSuccess;
+    if (!c->p1_desc_f.empty())
+      e = hipMemcpy(c->p1_desc_f_dev, c->p1_desc_f.data(), c->p1_desc_f.size() * sizeof(P1PackDesc),
+                    hipMemcpyHostToDevice);
+    if (e == hipSuccess && !c->p1_desc_b.empty())
+      e = hipMemcpy(c->p1_desc_b_dev, c->p1_desc_b.data(), c->p1_desc_b.size() * sizeof(P1PackDesc),
+                    hipMemcpyHostToDevice);
+    if (e != hipSuccess) return fail((int)e, "descriptor upload failed");
+  }
   c->N = n;
   c->H = h;
   c->W = w;
@@ -1642,6 +1734,12 @@ int rln_forward(rln_ctx* c, const float* x, int n, int h, int w, int training, c
                             c->d3_fwd_np, c->d3_fwd_dt, s));
   if (c->d3_units_b > 0 && training && c->with_bwd)
     RLN_TRY(d3_pack_weights(c->params, c->d3_desc_b_dev, (int)c->d3_desc_b.size(), c->d3_units_b, c->d3_packed,
+                            c->d3_bwd_np, c->d3_bwd_dt, s));
+  if (c->p1_units_f > 0)
+    RLN_TRY(p1_pack_weights(c->params, c->p1_desc_f_dev, (int)c->p1_desc_f.size(), c->p1_units_f, c->d3_packed,
+                            c->d3_fwd_np, c->d3_fwd_dt, s));
+  if (c->p1_units_b > 0 && training && c->with_bwd)
+    RLN_TRY(p1_pack_weights(c->params, c->p1_desc_b_dev, (int)c->p1_desc_b.size(), c->p1_units_b, c->d3_packed,
                             c->d3_bwd_np, c->d3_bwd_dt, s));
   for (size_t k = 0; k < c->ops.size(); ++k) RLN_TRY(fwd_op(c, k, x, training, s));
   if (probs_out || feat_out) {
@@ -1855,6 +1953,59 @@ int rln_op_conv_bnrelu(const float* x, int n, int cin, int x_ctot, int x_coff, i
   }
   RLN_TRY(igemm_launch(kind, tile, p, n, s));
   if (stats) RLN_TRY(reduce_rows(p.stat_partial, nblk, (long long)cout * 2, stats, s));
+  return 0;
+}
+
+int rln_op_td_fwd(const float* x, int n, int cin, int x_ctot, int x_coff, int h, int w, const float* a, const float* b,
+                  const float* weight, const float* bias, int cout, const float* scale, float* out, int out_ctot,
+                  int out_coff, uint8_t* pool_idx, float* stats, int parts, int dtype, void* workspace,
+                  size_t workspace_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!x || !a || !b || !weight || !out || !pool_idx || !workspace) return fail(RLN_ERR_ARG, "null pointer");
+  if (parts < 1 || parts > 3 || dtype < 0 || dtype > 1 || (dtype == 1 && parts == 3))
+    return fail(RLN_ERR_ARG, "parts in 1..3 (f16: 1..2), dtype 0 (bf16) or 1 (f16)");
+  const size_t plane = (size_t)h * w, pplane = (size_t)(h / 2) * (w / 2);
+  P1Fwd p;
+  memset(&p, 0, sizeof(p));
+  p.S = x + (size_t)x_coff * plane;
+  p.ns = (long long)x_ctot * plane;
+  p.cs = (int)plane;
+  p.H = h;
+  p.W = w;
+  p.Cin = cin;
+  p.N = n;
+  p.pa = a;
+  p.pb = b;
+  p.bias = bias;
+  p.nscale = scale;
+  p.out = out + (size_t)out_coff * pplane;
+  p.out_ns = (long long)out_ctot * pplane;
+  p.out_cs = (int)pplane;
+  p.Cout = cout;
+  p.pool_idx = pool_idx;
+  if (!p1_fwd_supported(p)) return fail(RLN_ERR_UNSUPPORTED, "geometry not covered by the 1x1 transition forward kernel");
+  p1_fwd_plan(&p, parts);
+  Carver cv(workspace);
+  P1PackDesc* desc = cv.take<P1PackDesc>(1);
+  uint4* packed = cv.take<uint4>((size_t)p1_units_f(cin, cout) * parts * 64);
+  float* partial = stats ? cv.take<float>((size_t)p.bpg * cout * 2) : nullptr;
+  if (cv.off > workspace_bytes) return fail(RLN_ERR_WORKSPACE, "workspace of %zu bytes needed", cv.off);
+  P1PackDesc d;
+  d.w_off = 0;
+  d.cin = cin;
+  d.cout = cout;
+  d.wf_off = 0;
+  d.wb_off = -1;
+  d.unit_begin = 0;
+  d.n_units = p1_units_f(cin, cout);
+  hipError_t e = hipMemcpyAsync(desc, &d, sizeof(d), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);  // `d` is a stack object
+  if (e != hipSuccess) return fail((int)e, "descriptor upload failed");
+  RLN_TRY(p1_pack_weights(weight, desc, 1, d.n_units, packed, parts, dtype, s));
+  p.wpk = packed;
+  p.stat_partial = partial;
+  RLN_TRY(p1_fwd_launch(p, parts, dtype, s));
+  if (stats) RLN_TRY(reduce_rows(partial, p.bpg, (long long)cout * 2, stats, s));
   return 0;
 }
 

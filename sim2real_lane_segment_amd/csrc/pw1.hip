@@ -1,0 +1,316 @@
+// TransitionDown 1x1 kernels on the 16-bit MFMA pipe with split fp32 operands (see pw1.h).
+#include "pw1.h"
+
+#include <algorithm>
+#include <cstdio>
+
+#include "split16.h"
+
+namespace rln {
+
+constexpr int P1_LDS_BUDGET = 150 * 1024;
+
+// =============================================================================================
+// weight packing
+// =============================================================================================
+template <int DT, int NP>
+__global__ __launch_bounds__(256) void p1_pack_k(const float* __restrict__ params, const P1PackDesc* __restrict__ desc,
+                                                 int n_desc, int total_units, uint4* __restrict__ packed) {
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (unit >= total_units) return;
+  int d = 0;
+  while (d + 1 < n_desc && desc[d + 1].unit_begin <= unit) ++d;
+  const P1PackDesc q = desc[d];
+  int u = unit - q.unit_begin;
+  const int nf = q.wf_off >= 0 ? ((q.cout + 15) >> 4) * ((q.cin + 31) >> 5) : 0;
+  const bool backward = u >= nf;
+  if (backward) {
+    u -= nf;
+    if (q.wb_off < 0) return;
+  }
+  const int KS = backward ? (q.cout + 31) >> 5 : (q.cin + 31) >> 5;
+  const int mtile = u / KS, ks = u - mtile * KS;
+  const int i = lane & 15, kb = lane >> 4;
+  const float* w = params + q.w_off;
+  const int row = mtile * 16 + i;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = ks * 32 + kb * 8 + e;
+    float val = 0.f;
+    if (!backward) {
+      if (row < q.cout && k < q.cin) val = w[(long long)row * q.cin + k];
+    } else {
+      if (row < q.cin && k < q.cout) val = w[(long long)k * q.cin + row];
+    }
+    v[e] = val;
+  }
+  unsigned parts[4][NP];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) split2<DT, NP>(v[2 * j], v[2 * j + 1], parts[j]);
+  uint4* dst = packed + (backward ? q.wb_off : q.wf_off) + ((long long)(mtile * KS + ks) * NP) * 64 + lane;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) dst[p * 64] = make_uint4(parts[0][p], parts[1][p], parts[2][p], parts[3][p]);
+}
+
+int p1_pack_weights(const float* params, const P1PackDesc* desc_dev, int n_desc, int total_units, uint4* packed, int np,
+                    int dt, hipStream_t s) {
+  if (total_units <= 0) return 0;
+  dim3 grid((unsigned)((total_units + 3) / 4));
+#define P1_PACK(DT_, NP_)                                                                                         \
+  hipLaunchKernelGGL((p1_pack_k<DT_, NP_>), grid, dim3(256), 0, s, params, desc_dev, n_desc, total_units, packed)
+  if (dt == D3_BF16) {
+    if (np == 1) P1_PACK(D3_BF16, 1);
+    else if (np == 2) P1_PACK(D3_BF16, 2);
+    else P1_PACK(D3_BF16, 3);
+  } else {
+    if (np == 1) P1_PACK(D3_F16, 1);
+    else if (np == 2) P1_PACK(D3_F16, 2);
+    else P1_PACK(D3_F16, 3);
+  }
+#undef P1_PACK
+  return (int)hipGetLastError();
+}
+
+// M tiles per block such that the block's weight fragments fit in LDS, balanced over the groups
+static void p1_group_plan(int m_tiles, int ksteps, int np, int extra_bytes_per_mtile, int* mt, int* groups) {
+  const int per = ksteps * np * 1024 + extra_bytes_per_mtile;
+  int cap = (P1_LDS_BUDGET - 2 * ksteps * 32 * 4) / per;
+  cap = std::max(1, std::min(8, cap));
+  *groups = (m_tiles + cap - 1) / cap;
+  *mt = (m_tiles + *groups - 1) / *groups;
+}
+
+// =============================================================================================
+// forward
+//
+// Block = 8 waves, persistent: holds the weight fragments of `mt` M tiles (16 output channels each) in LDS and walks wave
+// tiles of 16 pooling windows.  Per 32-channel K step a lane loads the 2x2 pixels of its window for its 8 channels (two
+// 8-byte loads per channel), applies BN + ReLU, splits into 16-bit parts (these registers are the B fragments of the four
+// window positions) and multiplies them with every M tile; the next K step's loads (or the first of the next wave tile)
+// are issued before the MFMAs.  Epilogue: (acc + bias) * scale, maximum over the four positions (first maximum wins, as
+// MaxPool2d), pooled value and argmax stored, per-channel sums of the pooled map reduced over the 16 windows with DPP
+// and accumulated in the wave's own LDS slots (fixed order: deterministic).
+// =============================================================================================
+template <int NP, int DT>
+__global__ __launch_bounds__(512, 2) void p1_fwd_k(const P1Fwd p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n16 = lane & 15, kb = lane >> 4;
+  const int KS = (p.Cin + 31) >> 5;
+  const int g = blockIdx.x / p.bpg, b = blockIdx.x - g * p.bpg;
+  const int m0 = g * p.mt;
+  const int mt = min(p.mt, ((p.Cout + 15) >> 4) - m0);
+  uint4* wl = reinterpret_cast<uint4*>(smem);                                         // [mt][KS][NP][64]
+  float* abtab = reinterpret_cast<float*>(smem + (size_t)p.mt * KS * NP * 1024);       // [2][KS*32]
+  float* slot = abtab + 2 * KS * 32;                                                   // [8][p.mt*16][2]
+  {
+    const uint4* src = p.wpk + (long long)m0 * KS * NP * 64;
+    const int cnt = mt * KS * NP * 64;
+    for (int i = tid; i < cnt; i += 512) wl[i] = src[i];
+    for (int i = tid; i < KS * 32; i += 512) {
+      abtab[i] = i < p.Cin ? p.pa[i] : 0.f;
+      abtab[KS * 32 + i] = i < p.Cin ? p.pb[i] : 0.f;
+    }
+    for (int i = tid; i < 8 * p.mt * 32; i += 512) slot[i] = 0.f;
+  }
+  __syncthreads();
+
+  const int PH = p.H >> 1, PW = p.W >> 1, PP = PH * PW;
+  const int total = p.N * PP;
+  const int ntiles = (total + 15) >> 4;
+  const int tstride = p.bpg * 8;
+
+  struct Tile {
+    const float* base;
+    int ns_, poff;
+    bool valid;
+  };
+  auto setup_tile = [&](int T) __attribute__((always_inline)) {
+    int v = T * 16 + n16;
+    Tile t;
+    t.valid = v < total;
+    if (!t.valid) v = total - 1;
+    t.ns_ = v / PP;
+    t.poff = v - t.ns_ * PP;
+    const int wy = t.poff / PW, wx = t.poff - wy * PW;
+    t.base = p.S + (long long)t.ns_ * p.ns + (long long)(2 * wy) * p.W + 2 * wx;
+    return t;
+  };
+
+  float2 r0[8], r1[8];
+  auto issue = [&](const float* base, int ks) __attribute__((always_inline)) {
+    // Cin % 8 == 0: an 8-channel block is all-in or all-out; blocks past Cin re-read the last block (their folded
+    // scale / shift in abtab is zero, so they contribute relu(0) = 0)
+    const float* q = base + (long long)min(ks * 32 + kb * 8, p.Cin - 8) * p.cs;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      r0[e] = *reinterpret_cast<const float2*>(q + e * p.cs);
+      r1[e] = *reinterpret_cast<const float2*>(q + e * p.cs + p.W);
+    }
+  };
+  uint4 bf[4][NP];
+  auto convert = [&](int ks) __attribute__((always_inline)) {
+    const float4* ap = reinterpret_cast<const float4*>(abtab + ks * 32 + kb * 8);
+    const float4* bp = reinterpret_cast<const float4*>(abtab + KS * 32 + ks * 32 + kb * 8);
+    const float4 a0 = ap[0], a1 = ap[1], b0 = bp[0], b1 = bp[1];
+    const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    float z[4][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      z[0][e] = fmaxf(fmaf(av[e], r0[e].x, bv[e]), 0.f);
+      z[1][e] = fmaxf(fmaf(av[e], r0[e].y, bv[e]), 0.f);
+      z[2][e] = fmaxf(fmaf(av[e], r1[e].x, bv[e]), 0.f);
+      z[3][e] = fmaxf(fmaf(av[e], r1[e].y, bv[e]), 0.f);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      unsigned w[4][NP];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) split2<DT, NP>(z[t][2 * j], z[t][2 * j + 1], w[j]);
+#pragma unroll
+      for (int pt = 0; pt < NP; ++pt) bf[t][pt] = make_uint4(w[0][pt], w[1][pt], w[2][pt], w[3][pt]);
+    }
+  };
+
+  f32x4 acc[8][4];
+  int T = b * 8 + wave;
+  Tile cur = setup_tile(min(T, ntiles - 1));
+  if (T < ntiles) issue(cur.base, 0);
+  while (T < ntiles) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int Tn = T + tstride;
+    Tile nxt = cur;
+    for (int ks = 0; ks < KS; ++ks) {
+      convert(ks);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + 1 < KS) {
+        issue(cur.base, ks + 1);
+      } else if (Tn < ntiles) {
+        nxt = setup_tile(Tn);
+        issue(nxt.base, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        if (m < mt) {
+          uint4 A[NP];
+#pragma unroll
+          for (int pt = 0; pt < NP; ++pt) A[pt] = wl[((m * KS + ks) * NP + pt) * 64 + lane];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[m][t] = mfma_split<DT, NP>(A, bf[t], acc[m][t]);
+        }
+      }
+    }
+    // ---- epilogue ----
+    int kb4 = 4 * kb;
+    asm volatile("" : "+v"(kb4));  // per-iteration opaque: keeps the 64 channel addresses out of loop-invariant registers
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      if (m < mt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ol = m * 16 + kb4 + r;
+          const int o = m0 * 16 + ol;
+          const bool ov = o < p.Cout;
+          const int oc = ov ? o : p.Cout - 1;
+          const float bias = p.bias ? p.bias[oc] : 0.f;
+          const float sc = p.nscale ? p.nscale[(long long)cur.ns_ * p.Cout + oc] : 1.f;
+          float best = (acc[m][0][r] + bias) * sc;
+          int bi = 0;
+#pragma unroll
+          for (int t = 1; t < 4; ++t) {
+            const float v = (acc[m][t][r] + bias) * sc;
+            if (v > best) {
+              best = v;
+              bi = t;
+            }
+          }
+          const bool st = ov && cur.valid;
+          if (st) {
+            p.out[(long long)cur.ns_ * p.out_ns + (long long)o * p.out_cs + cur.poff] = best;
+            p.pool_idx[((long long)cur.ns_ * p.Cout + o) * PP + cur.poff] = (unsigned char)bi;
+          }
+          const float s1 = row16_sum(st ? best : 0.f);
+          const float s2 = row16_sum(st ? best * best : 0.f);
+          if (n16 == 0) {
+            float* sl = slot + ((wave * p.mt * 16) + ol) * 2;
+            sl[0] += s1;
+            sl[1] += s2;
+          }
+        }
+      }
+    }
+    T = Tn;
+    cur = nxt;
+  }
+  __syncthreads();
+  if (p.stat_partial != nullptr && tid < mt * 16) {
+    const int o = m0 * 16 + tid;
+    if (o < p.Cout) {
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) {
+        a1 += slot[((w * p.mt * 16) + tid) * 2 + 0];
+        a2 += slot[((w * p.mt * 16) + tid) * 2 + 1];
+      }
+      p.stat_partial[((long long)b * p.Cout + o) * 2 + 0] = a1;
+      p.stat_partial[((long long)b * p.Cout + o) * 2 + 1] = a2;
+    }
+  }
+}
+
+static inline bool al8(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 7) == 0; }
+
+bool p1_fwd_supported(const P1Fwd& p) {
+  if (p.H < 2 || p.W < 2 || (p.W & 1) || (p.ns & 1) || (p.cs & 1) || !al8(p.S)) return false;
+  if (p.Cin < 8 || (p.Cin & 7) || p.Cout < 1 || p.N < 1) return false;
+  if ((long long)p.N * (p.H / 2) * (p.W / 2) + 16 >= (1ll << 31) || (long long)8 * p.cs + p.W >= (1ll << 31)) return false;
+  return true;
+}
+
+void p1_fwd_plan(P1Fwd* p, int np) {
+  const int KS = (p->Cin + 31) / 32;
+  p1_group_plan((p->Cout + 15) / 16, KS, np, 8 * 16 * 2 * 4, &p->mt, &p->groups);
+  const long long total = (long long)p->N * (p->H / 2) * (p->W / 2);
+  const long long ntiles = (total + 15) / 16;
+  p->bpg = (int)std::max(1ll, std::min((ntiles + 7) / 8, (long long)std::max(1, 256 / p->groups)));
+}
+
+template <int NP, int DT>
+static int p1_fwd_launch_t(const P1Fwd& p, hipStream_t s) {
+  const int KS = (p.Cin + 31) / 32;
+  const size_t lds = (size_t)p.mt * KS * NP * 1024 + (size_t)2 * KS * 32 * 4 + (size_t)8 * p.mt * 32 * 4;
+  if (lds > 160 * 1024) return -4;
+  auto kern = p1_fwd_k<NP, DT>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    (void)hipGetLastError();
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.groups * p.bpg)), dim3(512), lds, s, p);
+  return (int)hipGetLastError();
+}
+
+int p1_fwd_launch(const P1Fwd& p, int np, int dt, hipStream_t s) {
+  if (!p1_fwd_supported(p) || p.mt < 1 || p.mt > 8 || p.groups < 1 || p.bpg < 1) return -4;
+  if (p.mt * p.groups * 16 < p.Cout) return -4;
+  if (dt == D3_BF16) {
+    if (np == 1) return p1_fwd_launch_t<1, D3_BF16>(p, s);
+    if (np == 2) return p1_fwd_launch_t<2, D3_BF16>(p, s);
+    if (np == 3) return p1_fwd_launch_t<3, D3_BF16>(p, s);
+  } else if (dt == D3_F16) {
+    if (np == 1) return p1_fwd_launch_t<1, D3_F16>(p, s);
+    if (np == 2) return p1_fwd_launch_t<2, D3_F16>(p, s);
+  }
+  return -4;
+}
+
+}  // namespace rln
