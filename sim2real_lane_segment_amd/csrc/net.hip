@@ -536,6 +536,17 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
         const long long items = (long long)n * ((Hs + wth - 1) / wth) * ((Ws + wtw - 1) / wtw);
         const long long nch = wgrad_chunks(items, (o.cout + 63) / 64, (o.cin + 63) / 64, &ipc);
         wp_max = std::max(wp_max, (size_t)nch * o.cout * o.cin);
+        if (c->d3_bwd_np > 0) {
+          P1Wgrad g;
+          memset(&g, 0, sizeof(g));
+          g.Cout = o.cout;
+          g.Cin = o.cin;
+          g.H = Hs;
+          g.W = Ws;
+          g.N = n;
+          p1_wgrad_plan(&g);
+          wp_max = std::max(wp_max, (size_t)g.nranges * o.cout * o.cin);
+        }
       }
     } else {  // OP_TU
       const int GHc = (Hd + 1) / 2, GWc = (Wd + 1) / 2;
@@ -1226,6 +1237,97 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
     const Level& sl = c->levels[o.src_level];
     const Level& dl = c->levels[o.dst_level];
     const size_t splane = (size_t)sl.H * sl.W, dplane = (size_t)dl.H * dl.W;
+    if (c->d3_bwd_np > 0 && c->p1_wb_off[k] >= 0 && dl.H == sl.H / 2 && dl.W == sl.W / 2) {
+      // split-operand 16-bit MFMA kernels (pw1.h): the pooled gradient stays pooled; both kernels un-pool it on the fly
+      const int64_t so = sl.stat_off + o.in_off;
+      P1Dgrad q;
+      memset(&q, 0, sizeof(q));
+      q.dYp = c->dY;
+      q.pool_idx = c->pool_idx + c->pool_off[k];
+      q.Cout = o.cout;
+      q.wpk = c->d3_packed + c->p1_wb_off[k];
+      q.ea = c->ab + o.bn.ab;
+      q.eb = c->ab + c->n_ab + o.bn.ab;
+      q.egamma = c->params + o.bn.gamma;
+      q.mean = c->mean + so;
+      q.invstd = c->invstd + so;
+      q.S = sl.S + (size_t)o.in_off * splane;
+      q.ns = (long long)sl.C * splane;
+      q.cs = (int)splane;
+      q.G = sl.G + (size_t)o.in_off * splane;
+      q.C = o.cin;
+      q.acc_lo = o.acc_lo;
+      q.acc_hi = o.acc_hi;
+      q.H = sl.H;
+      q.W = sl.W;
+      q.N = N;
+      q.stat_partial = c->stat_partial;
+      P1Wgrad g;
+      memset(&g, 0, sizeof(g));
+      g.dYp = c->dY;
+      g.pool_idx = q.pool_idx;
+      g.Cout = o.cout;
+      g.S = q.S;
+      g.ns = q.ns;
+      g.cs = q.cs;
+      g.H = sl.H;
+      g.W = sl.W;
+      g.N = N;
+      g.Cin = o.cin;
+      g.pa = q.ea;
+      g.pb = q.eb;
+      g.partial = c->wpartial;
+      if (p1_dgrad_supported(q) && p1_wgrad_supported(g)) {
+        {  // finalise the pooled gradient (BatchNorm-backward correction of the level below, Dropout2d scale)
+          GradFinParams f;
+          memset(&f, 0, sizeof(f));
+          f.S = dl.S + (size_t)o.out_off * dplane;
+          f.G = dl.G + (size_t)o.out_off * dplane;
+          f.ns = (long long)dl.C * dplane;
+          f.C = o.cout;
+          f.H = dl.H;
+          f.W = dl.W;
+          const int64_t sd = dl.stat_off + o.out_off;
+          f.mean = c->mean + sd;
+          f.invstd = c->invstd + sd;
+          f.S1 = c->S1 + sd;
+          f.S2 = c->S2 + sd;
+          f.invM = (float)(1.0 / ((double)N * dplane));
+          f.nscale = c->masks + (size_t)N * o.drop_ch;
+          f.dst = c->dY;
+          f.bias_partial = c->bpartial;
+          f.Hd = dl.H;
+          f.Wd = dl.W;
+          ProfScope ps(c, PC_GRADFIN, 0, 12.0 * N * o.cout * dplane, s);
+          RLN_TRY(grad_finalize(f, N, &rows, s));
+          RLN_TRY(reduce_rows(c->bpartial, rows, o.cout, c->grads + o.conv.b, s));
+        }
+        p1_dgrad_plan(&q, c->d3_bwd_np);
+        {
+          const double flops = 2.0 * o.cin * o.cout * splane * N;
+          const double bytes = 4.0 * N * (1.25 * o.cout * dplane + 3.0 * o.cin * splane);
+          ProfScope ps(c, PC_TD_DGRAD, flops, bytes, s);
+          RLN_TRY(p1_dgrad_launch(q, c->d3_bwd_np, c->d3_bwd_dt, s));
+        }
+        RLN_TRY(bn_bwd_finalize(c->stat_partial, q.bpg, o.cin, c->params + o.bn.gamma, c->grads + o.bn.gamma,
+                                c->grads + o.bn.beta, c->S1 + so, c->S2 + so, s));
+        p1_wgrad_plan(&g);
+        RLN_TRY(wg_begin(c, s, &ws));
+        {
+          const double flops = 2.0 * o.cin * o.cout * splane * N;
+          const double bytes = 4.0 * N * (1.25 * o.cout * dplane + (double)o.cin * splane);
+          ProfScope ps(c, PC_TD_WGRAD, flops, bytes, ws);
+          RLN_TRY(p1_wgrad_launch(g, c->d3_bwd_np, c->d3_bwd_dt, ws));
+        }
+        {
+          const long long wsize = (long long)o.cout * o.cin;
+          ProfScope ps2(c, PC_REDUCE, 0, 4.0 * (g.nranges + 1) * wsize, ws);
+          RLN_TRY(reduce_rows(c->wpartial, g.nranges, wsize, c->grads + o.conv.w, ws));
+        }
+        RLN_TRY(wg_end(c));
+        return 0;
+      }
+    }
     {  // pooled gradient -> pre-pool map (MaxPool2d backward) with the Dropout2d scale
       GradFinParams g;
       memset(&g, 0, sizeof(g));

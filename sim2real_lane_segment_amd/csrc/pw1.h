@@ -89,10 +89,10 @@ struct P1Wgrad {
   const float* pb;
   float* partial;  // [nranges][Cout][Cin]
   int mo;          // M tiles (16 output channels each) per block
-  int ogroups, cblocks, nranges;
+  int ogroups, cblocks, nranges, per;  // output-channel groups, 128-input-channel blocks, K ranges of `per` slabs
 };
 bool p1_wgrad_supported(const P1Wgrad& p);
-void p1_wgrad_plan(P1Wgrad* p, int max_ranges);
+void p1_wgrad_plan(P1Wgrad* p);  // fills mo, ogroups, cblocks, nranges, per
 int p1_wgrad_launch(const P1Wgrad& p, int np, int dt, hipStream_t s);
 
 }  // namespace rln

@@ -313,4 +313,492 @@ int p1_fwd_launch(const P1Fwd& p, int np, int dt, hipStream_t s) {
   return -4;
 }
 
+// =============================================================================================
+// data gradient
+//
+// Same skeleton as the forward with M = input channels, K = output channels.  The B operand is the un-pooled gradient:
+// a lane loads the pooled value and the argmax byte of its window for its 8 output channels, splits the value once and
+// masks it into the window position the index names (the other three positions are zero), so the sparse pre-pool map is
+// never written to memory.  Epilogue per input channel: ReLU mask from S, BatchNorm-backward sums (sum gz, sum gz*xhat;
+// DPP row sums into the wave's LDS slots), G (+)= gamma * gz.  Odd H: the last row has no window (its gz is zero); it is
+// covered by an extra window row whose second pixel row lies outside the image.
+// =============================================================================================
+template <int NP, int DT>
+__global__ __launch_bounds__(512, 2) void p1_dgrad_k(const P1Dgrad p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n16 = lane & 15, kb = lane >> 4;
+  const int KS = (p.Cout + 31) >> 5;
+  const int g = blockIdx.x / p.bpg, b = blockIdx.x - g * p.bpg;
+  const int m0 = g * p.mt;
+  const int mt = min(p.mt, ((p.C + 15) >> 4) - m0);
+  uint4* wl = reinterpret_cast<uint4*>(smem);                                      // [mt][KS][NP][64]
+  float* chtab = reinterpret_cast<float*>(smem + (size_t)p.mt * KS * NP * 1024);    // [p.mt*16][8]
+  float* slot = chtab + p.mt * 16 * 8;                                              // [8][p.mt*16][2]
+  {
+    const uint4* src = p.wpk + (long long)m0 * KS * NP * 64;
+    const int cnt = mt * KS * NP * 64;
+    for (int i = tid; i < cnt; i += 512) wl[i] = src[i];
+    for (int i = tid; i < p.mt * 16; i += 512) {
+      const int c = m0 * 16 + i;
+      const bool cv = c < p.C;
+      float* t = chtab + i * 8;
+      t[0] = cv ? p.ea[c] : 0.f;
+      t[1] = cv ? p.eb[c] : 0.f;
+      t[2] = cv ? p.mean[c] : 0.f;
+      t[3] = cv ? p.invstd[c] : 0.f;
+      t[4] = cv ? p.egamma[c] : 0.f;
+      t[5] = (cv && c >= p.acc_lo && c < p.acc_hi) ? 1.f : 0.f;
+      t[6] = 0.f;
+      t[7] = 0.f;
+    }
+    for (int i = tid; i < 8 * p.mt * 32; i += 512) slot[i] = 0.f;
+  }
+  __syncthreads();
+
+  const int PH = p.H >> 1, PW = p.W >> 1, PP = PH * PW;
+  const int WR = (p.H + 1) >> 1, WP = WR * PW;
+  const int total = p.N * WP;
+  const int ntiles = (total + 15) >> 4;
+  const int tstride = p.bpg * 8;
+
+  struct Tile {
+    const float* gbase;          // dYp at (sample, channel 0, window)
+    const unsigned char* ibase;  // pool_idx, same
+    long long pix;               // pixel offset of the window's first row inside the sample (S / G views)
+    bool valid, win, row1;       // lane has a window slot / the window exists (pooled) / its second pixel row exists
+  };
+  auto setup_tile = [&](int T) __attribute__((always_inline)) {
+    int v = T * 16 + n16;
+    Tile t;
+    t.valid = v < total;
+    if (!t.valid) v = total - 1;
+    const int ns_ = v / WP;
+    const int rem = v - ns_ * WP;
+    const int wy = rem / PW, wx = rem - wy * PW;
+    t.win = t.valid && wy < PH;
+    t.row1 = 2 * wy + 1 < p.H;
+    const int poff = min(wy, PH - 1) * PW + wx;
+    t.gbase = p.dYp + (long long)ns_ * p.Cout * PP + poff;
+    t.ibase = p.pool_idx + (long long)ns_ * p.Cout * PP + poff;
+    t.pix = (long long)ns_ * p.ns + (long long)(2 * wy) * p.W + 2 * wx;
+    return t;
+  };
+
+  float gv[8];
+  unsigned char iv[8];
+  auto issue = [&](const Tile& t, int ks) __attribute__((always_inline)) {
+    const long long off = (long long)min(ks * 32 + kb * 8, p.Cout - 8) * PP;  // Cout % 8 == 0; weights past Cout are zero
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      gv[e] = t.gbase[off + (long long)e * PP];
+      iv[e] = t.ibase[off + (long long)e * PP];
+    }
+  };
+  uint4 bf[4][NP];
+  auto convert = [&](bool win) __attribute__((always_inline)) {
+    unsigned w[4][NP];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split2<DT, NP>(win ? gv[2 * j] : 0.f, win ? gv[2 * j + 1] : 0.f, w[j]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      unsigned mk[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        mk[j] = ((int)iv[2 * j] == t ? 0x0000FFFFu : 0u) | ((int)iv[2 * j + 1] == t ? 0xFFFF0000u : 0u);
+#pragma unroll
+      for (int pt = 0; pt < NP; ++pt)
+        bf[t][pt] = make_uint4(w[0][pt] & mk[0], w[1][pt] & mk[1], w[2][pt] & mk[2], w[3][pt] & mk[3]);
+    }
+  };
+
+  f32x4 acc[8][4];
+  int T = b * 8 + wave;
+  Tile cur = setup_tile(min(T, ntiles - 1));
+  if (T < ntiles) issue(cur, 0);
+  while (T < ntiles) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int Tn = T + tstride;
+    Tile nxt = cur;
+    for (int ks = 0; ks < KS; ++ks) {
+      convert(cur.win);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + 1 < KS) {
+        issue(cur, ks + 1);
+      } else if (Tn < ntiles) {
+        nxt = setup_tile(Tn);
+        issue(nxt, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        if (m < mt) {
+          uint4 A[NP];
+#pragma unroll
+          for (int pt = 0; pt < NP; ++pt) A[pt] = wl[((m * KS + ks) * NP + pt) * 64 + lane];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[m][t] = mfma_split<DT, NP>(A, bf[t], acc[m][t]);
+        }
+      }
+    }
+    // ---- epilogue ----
+    int kb4 = 4 * kb;
+    asm volatile("" : "+v"(kb4));  // per-iteration opaque: keeps the channel addresses out of loop-invariant registers
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      if (m < mt) {
+        float2 s0[4], s1[4], g0[4], g1[4];
+        bool cvr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int cl = m * 16 + kb4 + r;
+          const int c = m0 * 16 + cl;
+          cvr[r] = c < p.C && cur.valid;
+          const long long off = cur.pix + (long long)min(c, p.C - 1) * p.cs;
+          const long long off1 = cur.row1 ? off + p.W : off;
+          s0[r] = *reinterpret_cast<const float2*>(p.S + off);
+          s1[r] = *reinterpret_cast<const float2*>(p.S + off1);
+          g0[r] = *reinterpret_cast<const float2*>(p.G + off);
+          g1[r] = *reinterpret_cast<const float2*>(p.G + off1);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int cl = m * 16 + kb4 + r;
+          const int c = m0 * 16 + cl;
+          const float4 t0 = *reinterpret_cast<const float4*>(chtab + cl * 8);
+          const float2 t1 = *reinterpret_cast<const float2*>(chtab + cl * 8 + 4);
+          const float ea = t0.x, eb = t0.y, mean = t0.z, is = t0.w, egam = t1.x;
+          const bool accum = t1.y != 0.f;
+          const float sv[4] = {s0[r].x, s0[r].y, s1[r].x, s1[r].y};
+          const float go[4] = {g0[r].x, g0[r].y, g1[r].x, g1[r].y};
+          float ov[4];
+          float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const bool pv = cvr[r] && (t < 2 || cur.row1);
+            const float yv = fmaf(ea, sv[t], eb);
+            const float gz = (pv && yv > 0.f) ? acc[m][t][r] : 0.f;
+            const float xh = (sv[t] - mean) * is;
+            a1 += gz;
+            a2 += gz * xh;
+            ov[t] = fmaf(egam, gz, accum ? go[t] : 0.f);
+          }
+          if (cvr[r]) {
+            const long long off = cur.pix + (long long)c * p.cs;
+            *reinterpret_cast<float2*>(p.G + off) = make_float2(ov[0], ov[1]);
+            if (cur.row1) *reinterpret_cast<float2*>(p.G + off + p.W) = make_float2(ov[2], ov[3]);
+          }
+          a1 = row16_sum(a1);
+          a2 = row16_sum(a2);
+          if (n16 == 0) {
+            float* sl = slot + ((wave * p.mt * 16) + cl) * 2;
+            sl[0] += a1;
+            sl[1] += a2;
+          }
+        }
+      }
+    }
+    T = Tn;
+    cur = nxt;
+  }
+  __syncthreads();
+  if (p.stat_partial != nullptr && tid < mt * 16) {
+    const int c = m0 * 16 + tid;
+    if (c < p.C) {
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) {
+        a1 += slot[((w * p.mt * 16) + tid) * 2 + 0];
+        a2 += slot[((w * p.mt * 16) + tid) * 2 + 1];
+      }
+      p.stat_partial[((long long)b * p.C + c) * 2 + 0] = a1;
+      p.stat_partial[((long long)b * p.C + c) * 2 + 1] = a2;
+    }
+  }
+}
+
+bool p1_dgrad_supported(const P1Dgrad& p) {
+  if (p.H < 2 || p.W < 2 || (p.W & 1) || (p.ns & 1) || (p.cs & 1) || !al8(p.S) || !al8(p.G)) return false;
+  if (p.C < 1 || p.Cout < 8 || (p.Cout & 7) || p.N < 1) return false;
+  if ((long long)p.N * ((p.H + 1) / 2) * (p.W / 2) + 16 >= (1ll << 31)) return false;
+  return true;
+}
+
+void p1_dgrad_plan(P1Dgrad* p, int np) {
+  const int KS = (p->Cout + 31) / 32;
+  p1_group_plan((p->C + 15) / 16, KS, np, 16 * 8 * 4 + 8 * 16 * 2 * 4, &p->mt, &p->groups);
+  const long long total = (long long)p->N * ((p->H + 1) / 2) * (p->W / 2);
+  const long long ntiles = (total + 15) / 16;
+  p->bpg = (int)std::max(1ll, std::min((ntiles + 7) / 8, (long long)std::max(1, 256 / p->groups)));
+}
+
+template <int NP, int DT>
+static int p1_dgrad_launch_t(const P1Dgrad& p, hipStream_t s) {
+  const int KS = (p.Cout + 31) / 32;
+  const size_t lds = (size_t)p.mt * KS * NP * 1024 + (size_t)p.mt * 16 * 8 * 4 + (size_t)8 * p.mt * 32 * 4;
+  if (lds > 160 * 1024) return -4;
+  auto kern = p1_dgrad_k<NP, DT>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    (void)hipGetLastError();
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.groups * p.bpg)), dim3(512), lds, s, p);
+  return (int)hipGetLastError();
+}
+
+int p1_dgrad_launch(const P1Dgrad& p, int np, int dt, hipStream_t s) {
+  if (!p1_dgrad_supported(p) || p.mt < 1 || p.mt > 8 || p.groups < 1 || p.bpg < 1) return -4;
+  if (p.mt * p.groups * 16 < p.C) return -4;
+  if (dt == D3_BF16) {
+    if (np == 1) return p1_dgrad_launch_t<1, D3_BF16>(p, s);
+    if (np == 2) return p1_dgrad_launch_t<2, D3_BF16>(p, s);
+    if (np == 3) return p1_dgrad_launch_t<3, D3_BF16>(p, s);
+  } else if (dt == D3_F16) {
+    if (np == 1) return p1_dgrad_launch_t<1, D3_F16>(p, s);
+    if (np == 2) return p1_dgrad_launch_t<2, D3_F16>(p, s);
+  }
+  return -4;
+}
+
+// =============================================================================================
+// weight gradient
+//
+// K = pixels.  A K step is 8 pooling windows x 4 positions; lane (i = l&15, kb = l>>4) holds windows 2kb, 2kb+1.
+//   A[o][k] = un-pooled gradient: expanded from (pooled value, argmax byte) -- staged through LDS once per block and
+//             shared by its 4 waves (two K steps = one 16-window "slab" per barrier, double buffered);
+//   B[k][c] = relu(a*S + b): each wave owns two 16-channel N tiles and loads its lanes' window pixels straight from the
+//             NCHW planes (two 8-byte loads per window), so every activation is read once per output-channel group.
+// Block = (K range, output-channel group of <= 8 M tiles, 128-input-channel block); accumulators stay in registers over
+// the whole range, partial[range][o][c] is reduced afterwards (fixed order).  Slabs never straddle samples; windows past
+// the end of a sample's window plane carry zero gradient.
+// =============================================================================================
+template <int NP, int DT>
+__global__ __launch_bounds__(256, 2) void p1_wgrad_k(const P1Wgrad p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n16 = lane & 15, kb = lane >> 4;
+  uint4* abuf = reinterpret_cast<uint4*>(smem);  // [2 buffers][2 ksteps][8 m][NP][64]
+  constexpr int ABUF = 2 * 8 * NP * 64;          // uint4 units per buffer
+
+  const int cb = blockIdx.x % p.cblocks;
+  const int og = (blockIdx.x / p.cblocks) % p.ogroups;
+  const int range = blockIdx.x / (p.cblocks * p.ogroups);
+  const int MTtot = (p.Cout + 15) >> 4;
+  const int mo = min(p.mo, MTtot - og * p.mo);
+  const int PH = p.H >> 1, PW = p.W >> 1, PP = PH * PW;
+  const int SL = (PP + 15) >> 4;
+  const int slab_begin = range * p.per, slab_end = min(p.N * SL, slab_begin + p.per);
+
+  // B side: this wave's two N tiles
+  int cch[2];
+  float ba[2], bb[2];
+  const float* sb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = (cb * 8 + 2 * wave + i) * 16 + n16;
+    cch[i] = c;
+    const int cc = min(c, p.Cin - 1);
+    ba[i] = c < p.Cin ? p.pa[cc] : 0.f;
+    bb[i] = c < p.Cin ? p.pb[cc] : 0.f;
+    sb[i] = p.S + (long long)cc * p.cs;
+  }
+  const bool wave_active = (cb * 8 + 2 * wave) * 16 < p.Cin;
+
+  float2 raw[2][2][2][2];  // [kstep][tile][window][row]
+  auto issue_b = [&](int slab) __attribute__((always_inline)) {
+    const int ns_ = slab / SL;
+    const int w0 = (slab - ns_ * SL) * 16;
+#pragma unroll
+    for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int w = min(w0 + j2 * 8 + 2 * kb + j, PP - 1);
+        const int wy = w / PW, wx = w - wy * PW;
+        const long long off = (long long)ns_ * p.ns + (long long)(2 * wy) * p.W + 2 * wx;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          raw[j2][i][j][0] = *reinterpret_cast<const float2*>(sb[i] + off);
+          raw[j2][i][j][1] = *reinterpret_cast<const float2*>(sb[i] + off + p.W);
+        }
+      }
+  };
+  uint4 bfr[2][2][NP];
+  auto convert_b = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        unsigned w[4][NP];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float z0 = fmaxf(fmaf(ba[i], raw[j2][i][j][0].x, bb[i]), 0.f);
+          const float z1 = fmaxf(fmaf(ba[i], raw[j2][i][j][0].y, bb[i]), 0.f);
+          const float z2 = fmaxf(fmaf(ba[i], raw[j2][i][j][1].x, bb[i]), 0.f);
+          const float z3 = fmaxf(fmaf(ba[i], raw[j2][i][j][1].y, bb[i]), 0.f);
+          split2<DT, NP>(z0, z1, w[2 * j]);
+          split2<DT, NP>(z2, z3, w[2 * j + 1]);
+        }
+#pragma unroll
+        for (int pt = 0; pt < NP; ++pt) bfr[j2][i][pt] = make_uint4(w[0][pt], w[1][pt], w[2][pt], w[3][pt]);
+      }
+  };
+
+  // A side: thread builds entries (kstep j2, m, lane l) for e = tid + 256*q, q = 0..3 : l = e & 63, m = (e >> 6) & 7, j2 = e >> 9
+  float ag[4][2];
+  unsigned char ai[4][2];
+  auto issue_a = [&](int slab) __attribute__((always_inline)) {
+    const int ns_ = slab / SL;
+    const int w0 = (slab - ns_ * SL) * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = tid + 256 * q;
+      const int l = e & 63, m = (e >> 6) & 7, j2 = e >> 9;
+      const int o = min((og * p.mo + m) * 16 + (l & 15), p.Cout - 1);
+      const long long base = ((long long)ns_ * p.Cout + o) * PP;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int w = min(w0 + j2 * 8 + 2 * (l >> 4) + j, PP - 1);
+        ag[q][j] = p.dYp[base + w];
+        ai[q][j] = p.pool_idx[base + w];
+      }
+    }
+  };
+  auto commit_a = [&](int slab, int buf) __attribute__((always_inline)) {
+    const int ns_ = slab / SL;
+    const int w0 = (slab - ns_ * SL) * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = tid + 256 * q;
+      const int l = e & 63, m = (e >> 6) & 7, j2 = e >> 9;
+      const int wbase = w0 + j2 * 8 + 2 * (l >> 4);
+      const bool ov = (og * p.mo + m) * 16 + (l & 15) < p.Cout && m < mo;
+      const float g0 = (ov && wbase < PP) ? ag[q][0] : 0.f;
+      const float g1 = (ov && wbase + 1 < PP) ? ag[q][1] : 0.f;
+      unsigned h[NP];
+      split2<DT, NP>(g0, g1, h);
+      const int i0 = ai[q][0], i1 = ai[q][1];
+#pragma unroll
+      for (int pt = 0; pt < NP; ++pt) {
+        const unsigned lo = h[pt] & 0xFFFFu, hi = h[pt] >> 16;
+        uint4 v;
+        v.x = (i0 == 0 ? lo : 0u) | (i0 == 1 ? lo << 16 : 0u);
+        v.y = (i0 == 2 ? lo : 0u) | (i0 == 3 ? lo << 16 : 0u);
+        v.z = (i1 == 0 ? hi : 0u) | (i1 == 1 ? hi << 16 : 0u);
+        v.w = (i1 == 2 ? hi : 0u) | (i1 == 3 ? hi << 16 : 0u);
+        abuf[buf * ABUF + ((j2 * 8 + m) * NP + pt) * 64 + l] = v;
+      }
+    }
+  };
+
+  f32x4 acc[8][2];
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) acc[m][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (slab_begin < slab_end) {
+    issue_a(slab_begin);
+    issue_b(slab_begin);
+    commit_a(slab_begin, 0);
+  }
+  __syncthreads();
+  for (int s = slab_begin; s < slab_end; ++s) {
+    const int buf = (s - slab_begin) & 1;
+    const bool more = s + 1 < slab_end;
+    if (more) issue_a(s + 1);
+    convert_b();
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) issue_b(s + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (wave_active) {
+#pragma unroll
+      for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          if (m < mo) {
+            uint4 A[NP];
+#pragma unroll
+            for (int pt = 0; pt < NP; ++pt) A[pt] = abuf[buf * ABUF + ((j2 * 8 + m) * NP + pt) * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[m][i] = mfma_split<DT, NP>(A, bfr[j2][i], acc[m][i]);
+          }
+        }
+    }
+    if (more) commit_a(s + 1, buf ^ 1);
+    __syncthreads();
+  }
+  // ---- store: acc[m][i][r] = dW[o = 16*(og*mo+m) + 4*kb + r][c = cch[i]] ----
+  float* dst = p.partial + (long long)range * p.Cout * p.Cin;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    if (m < mo) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = (og * p.mo + m) * 16 + 4 * kb + r;
+        if (o < p.Cout) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            if (cch[i] < p.Cin) dst[(long long)o * p.Cin + cch[i]] = acc[m][i][r];
+        }
+      }
+    }
+  }
+}
+
+bool p1_wgrad_supported(const P1Wgrad& p) {
+  if (p.H < 2 || p.W < 2 || (p.W & 1) || (p.ns & 1) || (p.cs & 1) || !al8(p.S)) return false;
+  if (p.Cin < 1 || p.Cout < 1 || p.N < 1) return false;
+  if ((long long)p.N * (p.H / 2) * (p.W / 2) + 16 >= (1ll << 31)) return false;
+  return true;
+}
+
+void p1_wgrad_plan(P1Wgrad* p) {
+  const int MTtot = (p->Cout + 15) / 16;
+  p->ogroups = (MTtot + 7) / 8;
+  p->mo = (MTtot + p->ogroups - 1) / p->ogroups;
+  p->cblocks = ((p->Cin + 15) / 16 + 7) / 8;
+  const int PP = (p->H / 2) * (p->W / 2);
+  const long long slabs = (long long)p->N * ((PP + 15) / 16);
+  long long nr = std::max(1ll, std::min(slabs, (long long)std::max(1, 512 / (p->ogroups * p->cblocks))));
+  const long long per = (slabs + nr - 1) / nr;
+  p->per = (int)per;
+  p->nranges = (int)((slabs + per - 1) / per);
+}
+
+template <int NP, int DT>
+static int p1_wgrad_launch_t(const P1Wgrad& p, hipStream_t s) {
+  const size_t lds = (size_t)2 * 2 * 8 * NP * 1024;
+  auto kern = p1_wgrad_k<NP, DT>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    (void)hipGetLastError();
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.nranges * p.ogroups * p.cblocks)), dim3(256), lds, s, p);
+  return (int)hipGetLastError();
+}
+
+int p1_wgrad_launch(const P1Wgrad& p, int np, int dt, hipStream_t s) {
+  if (!p1_wgrad_supported(p) || p.mo < 1 || p.mo > 8 || p.ogroups < 1 || p.cblocks < 1 || p.nranges < 1 || p.per < 1)
+    return -4;
+  if (p.mo * p.ogroups * 16 < p.Cout || p.cblocks * 128 < p.Cin) return -4;
+  if (dt == D3_BF16) {
+    if (np == 1) return p1_wgrad_launch_t<1, D3_BF16>(p, s);
+    if (np == 2) return p1_wgrad_launch_t<2, D3_BF16>(p, s);
+    if (np == 3) return p1_wgrad_launch_t<3, D3_BF16>(p, s);
+  } else if (dt == D3_F16) {
+    if (np == 1) return p1_wgrad_launch_t<1, D3_F16>(p, s);
+    if (np == 2) return p1_wgrad_launch_t<2, D3_F16>(p, s);
+  }
+  return -4;
+}
+
 }  // namespace rln
