@@ -2106,6 +2106,9 @@ int rln_op_td_fwd(const float* x, int n, int cin, int x_ctot, int x_coff, int h,
   RLN_TRY(p1_pack_weights(weight, desc, 1, d.n_units, packed, parts, dtype, s));
   p.wpk = packed;
   p.stat_partial = partial;
+#ifdef RLN_DIAG
+  if (rln_env("RLN_P1_DBG")) p.dbg = atoi(rln_env("RLN_P1_DBG"));
+#endif
   RLN_TRY(p1_fwd_launch(p, parts, dtype, s));
   if (stats) RLN_TRY(reduce_rows(partial, p.bpg, (long long)cout * 2, stats, s));
   return 0;

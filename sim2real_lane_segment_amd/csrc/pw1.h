@@ -48,6 +48,7 @@ struct P1Fwd {
   unsigned char* pool_idx;  // [N][Cout][H/2][W/2]: 2*dy + dx of the (first) maximum
   float* stat_partial;      // [bpg][Cout][2] or null
   int mt, groups, bpg;      // M tiles per block, output-channel groups, blocks per group (p1_fwd_plan)
+  int dbg;                  // diagnostic builds (-DRLN_DIAG) only: 1 no global loads, 2 no MFMA phase, 4 no epilogue
 };
 bool p1_fwd_supported(const P1Fwd& p);
 void p1_fwd_plan(P1Fwd* p, int np);  // fills mt, groups, bpg from Cin, Cout, N, H, W

@@ -10,6 +10,10 @@ namespace rln {
 
 constexpr int P1_LDS_BUDGET = 150 * 1024;
 
+__device__ __forceinline__ void lds_add(float* p, float v) {
+  (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // =============================================================================================
 // weight packing
 // =============================================================================================
@@ -105,6 +109,7 @@ __global__ __launch_bounds__(512, 2) void p1_fwd_k(const P1Fwd p) {
   uint4* wl = reinterpret_cast<uint4*>(smem);                                         // [mt][KS][NP][64]
   float* abtab = reinterpret_cast<float*>(smem + (size_t)p.mt * KS * NP * 1024);       // [2][KS*32]
   float* slot = abtab + 2 * KS * 32;                                                   // [8][p.mt*16][2]
+  float* btab = slot + 8 * p.mt * 32;                                                  // [p.mt*16] bias
   {
     const uint4* src = p.wpk + (long long)m0 * KS * NP * 64;
     const int cnt = mt * KS * NP * 64;
@@ -114,6 +119,7 @@ __global__ __launch_bounds__(512, 2) void p1_fwd_k(const P1Fwd p) {
       abtab[KS * 32 + i] = i < p.Cin ? p.pb[i] : 0.f;
     }
     for (int i = tid; i < 8 * p.mt * 32; i += 512) slot[i] = 0.f;
+    for (int i = tid; i < p.mt * 16; i += 512) btab[i] = (p.bias && m0 * 16 + i < p.Cout) ? p.bias[m0 * 16 + i] : 0.f;
   }
   __syncthreads();
 
@@ -175,10 +181,20 @@ __global__ __launch_bounds__(512, 2) void p1_fwd_k(const P1Fwd p) {
     }
   };
 
+#ifdef RLN_DIAG
+  const int dbg = p.dbg;
+#else
+  constexpr int dbg = 0;
+#endif
+  if (dbg & 1) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r0[e] = r1[e] = make_float2(0.5f, -0.25f);
+  }
+  const bool sc_vec = (reinterpret_cast<uintptr_t>(p.nscale) & 15) == 0;
   f32x4 acc[8][4];
   int T = b * 8 + wave;
   Tile cur = setup_tile(min(T, ntiles - 1));
-  if (T < ntiles) issue(cur.base, 0);
+  if (T < ntiles && !(dbg & 1)) issue(cur.base, 0);
   while (T < ntiles) {
 #pragma unroll
     for (int m = 0; m < 8; ++m)
@@ -190,12 +206,16 @@ __global__ __launch_bounds__(512, 2) void p1_fwd_k(const P1Fwd p) {
       convert(ks);
       __builtin_amdgcn_sched_barrier(0);
       if (ks + 1 < KS) {
-        issue(cur.base, ks + 1);
+        if (!(dbg & 1)) issue(cur.base, ks + 1);
       } else if (Tn < ntiles) {
         nxt = setup_tile(Tn);
-        issue(nxt.base, 0);
+        if (!(dbg & 1)) issue(nxt.base, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (dbg & 2) {
+        asm volatile("" ::"v"(bf[0][0].x), "v"(bf[1][0].y), "v"(bf[2][0].z), "v"(bf[3][0].w));
+        continue;
+      }
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
         if (m < mt) {
@@ -210,17 +230,38 @@ __global__ __launch_bounds__(512, 2) void p1_fwd_k(const P1Fwd p) {
     // ---- epilogue ----
     int kb4 = 4 * kb;
     asm volatile("" : "+v"(kb4));  // per-iteration opaque: keeps the 64 channel addresses out of loop-invariant registers
+    if (dbg & 4) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) asm volatile("" ::"v"(acc[m][0][0]), "v"(acc[m][1][1]), "v"(acc[m][2][2]), "v"(acc[m][3][3]));
+      T = Tn;
+      cur = nxt;
+      continue;
+    }
+    // Dropout2d scales of the lane's sample for all its channels first (one 16-byte load per M tile, issued together):
+    // loads placed between the stores below could not be hoisted over them
+    float4 sc4[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      sc4[m] = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (m < mt && p.nscale != nullptr) {
+        const float* q = p.nscale + (long long)cur.ns_ * p.Cout + min(m0 * 16 + m * 16 + kb4, p.Cout - 4);
+        if (sc_vec) sc4[m] = *reinterpret_cast<const float4*>(q);
+        else sc4[m] = make_float4(q[0], q[1], q[2], q[3]);
+      }
+    }
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       if (m < mt) {
+        const float4 b4 = *reinterpret_cast<const float4*>(btab + m * 16 + kb4);
+        const float bia[4] = {b4.x, b4.y, b4.z, b4.w};
+        const float sca[4] = {sc4[m].x, sc4[m].y, sc4[m].z, sc4[m].w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int ol = m * 16 + kb4 + r;
           const int o = m0 * 16 + ol;
           const bool ov = o < p.Cout;
-          const int oc = ov ? o : p.Cout - 1;
-          const float bias = p.bias ? p.bias[oc] : 0.f;
-          const float sc = p.nscale ? p.nscale[(long long)cur.ns_ * p.Cout + oc] : 1.f;
+          const float bias = bia[r];
+          const float sc = sca[r];
           float best = (acc[m][0][r] + bias) * sc;
           int bi = 0;
 #pragma unroll
@@ -238,10 +279,10 @@ __global__ __launch_bounds__(512, 2) void p1_fwd_k(const P1Fwd p) {
           }
           const float s1 = row16_sum(st ? best : 0.f);
           const float s2 = row16_sum(st ? best * best : 0.f);
-          if (n16 == 0) {
+          if (n16 == 0) {  // LDS float adds without return: nothing to wait for; one wave per slot, issue order = sum order
             float* sl = slot + ((wave * p.mt * 16) + ol) * 2;
-            sl[0] += s1;
-            sl[1] += s2;
+            lds_add(sl, s1);
+            lds_add(sl + 1, s2);
           }
         }
       }
@@ -269,14 +310,14 @@ static inline bool al8(const void* q) { return (reinterpret_cast<uintptr_t>(q) &
 
 bool p1_fwd_supported(const P1Fwd& p) {
   if (p.H < 2 || p.W < 2 || (p.W & 1) || (p.ns & 1) || (p.cs & 1) || !al8(p.S)) return false;
-  if (p.Cin < 8 || (p.Cin & 7) || p.Cout < 1 || p.N < 1) return false;
+  if (p.Cin < 8 || (p.Cin & 7) || p.Cout < 4 || (p.Cout & 3) || p.N < 1) return false;
   if ((long long)p.N * (p.H / 2) * (p.W / 2) + 16 >= (1ll << 31) || (long long)8 * p.cs + p.W >= (1ll << 31)) return false;
   return true;
 }
 
 void p1_fwd_plan(P1Fwd* p, int np) {
   const int KS = (p->Cin + 31) / 32;
-  p1_group_plan((p->Cout + 15) / 16, KS, np, 8 * 16 * 2 * 4, &p->mt, &p->groups);
+  p1_group_plan((p->Cout + 15) / 16, KS, np, 8 * 16 * 2 * 4 + 16 * 4, &p->mt, &p->groups);
   const long long total = (long long)p->N * (p->H / 2) * (p->W / 2);
   const long long ntiles = (total + 15) / 16;
   p->bpg = (int)std::max(1ll, std::min((ntiles + 7) / 8, (long long)std::max(1, 256 / p->groups)));
@@ -285,7 +326,8 @@ void p1_fwd_plan(P1Fwd* p, int np) {
 template <int NP, int DT>
 static int p1_fwd_launch_t(const P1Fwd& p, hipStream_t s) {
   const int KS = (p.Cin + 31) / 32;
-  const size_t lds = (size_t)p.mt * KS * NP * 1024 + (size_t)2 * KS * 32 * 4 + (size_t)8 * p.mt * 32 * 4;
+  const size_t lds = (size_t)p.mt * KS * NP * 1024 + (size_t)2 * KS * 32 * 4 + (size_t)8 * p.mt * 32 * 4 +
+                     (size_t)p.mt * 16 * 4;
   if (lds > 160 * 1024) return -4;
   auto kern = p1_fwd_k<NP, DT>;
   static bool attr_done = false;
@@ -495,8 +537,8 @@ __global__ __launch_bounds__(512, 2) void p1_dgrad_k(const P1Dgrad p) {
           a2 = row16_sum(a2);
           if (n16 == 0) {
             float* sl = slot + ((wave * p.mt * 16) + cl) * 2;
-            sl[0] += a1;
-            sl[1] += a2;
+            lds_add(sl, a1);
+            lds_add(sl + 1, a2);
           }
         }
       }
@@ -578,7 +620,7 @@ int p1_dgrad_launch(const P1Dgrad& p, int np, int dt, hipStream_t s) {
 // the whole range, partial[range][o][c] is reduced afterwards (fixed order).  Slabs never straddle samples; windows past
 // the end of a sample's window plane carry zero gradient.
 // =============================================================================================
-template <int NP, int DT>
+template <int NP, int DT, bool V4>
 __global__ __launch_bounds__(256, 2) void p1_wgrad_k(const P1Wgrad p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -610,26 +652,49 @@ __global__ __launch_bounds__(256, 2) void p1_wgrad_k(const P1Wgrad p) {
   }
   const bool wave_active = (cb * 8 + 2 * wave) * 16 < p.Cin;
 
-  float2 raw[2][2][2][2];  // [kstep][tile][window][row]
-  auto issue_b = [&](int slab) __attribute__((always_inline)) {
+  // V4 (even window-row length, 16-byte aligned rows): a lane's two windows are horizontal neighbours, one 16-byte load
+  // per (tile, row, K step) and the two K steps of a slab consume each 128-byte line back to back.
+  typedef float2 RawSet[2][2][2][2];  // [kstep][tile][window][row]
+  RawSet rawA, rawB;                  // two slabs in flight
+  auto issue_b = [&](int slab, RawSet& raw) __attribute__((always_inline)) {
     const int ns_ = slab / SL;
     const int w0 = (slab - ns_ * SL) * 16;
+    if constexpr (V4) {
+      long long off[2];
 #pragma unroll
-    for (int j2 = 0; j2 < 2; ++j2)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int w = min(w0 + j2 * 8 + 2 * kb + j, PP - 1);
+      for (int j2 = 0; j2 < 2; ++j2) {
+        const int w = min(w0 + j2 * 8 + 2 * kb, PP - 2);
         const int wy = w / PW, wx = w - wy * PW;
-        const long long off = (long long)ns_ * p.ns + (long long)(2 * wy) * p.W + 2 * wx;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          raw[j2][i][j][0] = *reinterpret_cast<const float2*>(sb[i] + off);
-          raw[j2][i][j][1] = *reinterpret_cast<const float2*>(sb[i] + off + p.W);
-        }
+        off[j2] = (long long)ns_ * p.ns + (long long)(2 * wy) * p.W + 2 * wx;
       }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int row = 0; row < 2; ++row)
+#pragma unroll
+          for (int j2 = 0; j2 < 2; ++j2) {
+            const float4 v = *reinterpret_cast<const float4*>(sb[i] + off[j2] + row * p.W);
+            raw[j2][i][0][row] = make_float2(v.x, v.y);
+            raw[j2][i][1][row] = make_float2(v.z, v.w);
+          }
+    } else {
+#pragma unroll
+      for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int w = min(w0 + j2 * 8 + 2 * kb + j, PP - 1);
+          const int wy = w / PW, wx = w - wy * PW;
+          const long long off = (long long)ns_ * p.ns + (long long)(2 * wy) * p.W + 2 * wx;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            raw[j2][i][j][0] = *reinterpret_cast<const float2*>(sb[i] + off);
+            raw[j2][i][j][1] = *reinterpret_cast<const float2*>(sb[i] + off + p.W);
+          }
+        }
+    }
   };
   uint4 bfr[2][2][NP];
-  auto convert_b = [&]() __attribute__((always_inline)) {
+  auto convert_b = [&](const RawSet& raw) __attribute__((always_inline)) {
 #pragma unroll
     for (int j2 = 0; j2 < 2; ++j2)
 #pragma unroll
@@ -661,11 +726,21 @@ __global__ __launch_bounds__(256, 2) void p1_wgrad_k(const P1Wgrad p) {
       const int l = e & 63, m = (e >> 6) & 7, j2 = e >> 9;
       const int o = min((og * p.mo + m) * 16 + (l & 15), p.Cout - 1);
       const long long base = ((long long)ns_ * p.Cout + o) * PP;
+      if constexpr (V4) {  // PP even: the window pair is 8-byte (values) / 2-byte (indices) aligned
+        const int w = min(w0 + j2 * 8 + 2 * (l >> 4), PP - 2);
+        const float2 g2 = *reinterpret_cast<const float2*>(p.dYp + base + w);
+        const uchar2 i2 = *reinterpret_cast<const uchar2*>(p.pool_idx + base + w);
+        ag[q][0] = g2.x;
+        ag[q][1] = g2.y;
+        ai[q][0] = i2.x;
+        ai[q][1] = i2.y;
+      } else {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int w = min(w0 + j2 * 8 + 2 * (l >> 4) + j, PP - 1);
-        ag[q][j] = p.dYp[base + w];
-        ai[q][j] = p.pool_idx[base + w];
+        for (int j = 0; j < 2; ++j) {
+          const int w = min(w0 + j2 * 8 + 2 * (l >> 4) + j, PP - 1);
+          ag[q][j] = p.dYp[base + w];
+          ai[q][j] = p.pool_idx[base + w];
+        }
       }
     }
   };
@@ -704,17 +779,20 @@ __global__ __launch_bounds__(256, 2) void p1_wgrad_k(const P1Wgrad p) {
 
   if (slab_begin < slab_end) {
     issue_a(slab_begin);
-    issue_b(slab_begin);
+    issue_b(slab_begin, rawA);
+    if (slab_begin + 1 < slab_end) issue_b(slab_begin + 1, rawB);
     commit_a(slab_begin, 0);
   }
   __syncthreads();
-  for (int s = slab_begin; s < slab_end; ++s) {
+  // one slab: A(s+1) values requested, B(s) converted, B(s+2) requested into the registers just freed, MFMAs of slab s,
+  // A(s+1) committed to the other buffer, barrier
+  auto step = [&](int s, RawSet& raw) __attribute__((always_inline)) {
     const int buf = (s - slab_begin) & 1;
     const bool more = s + 1 < slab_end;
     if (more) issue_a(s + 1);
-    convert_b();
+    convert_b(raw);
     __builtin_amdgcn_sched_barrier(0);
-    if (more) issue_b(s + 1);
+    if (s + 2 < slab_end) issue_b(s + 2, raw);
     __builtin_amdgcn_sched_barrier(0);
     if (wave_active) {
 #pragma unroll
@@ -732,6 +810,10 @@ __global__ __launch_bounds__(256, 2) void p1_wgrad_k(const P1Wgrad p) {
     }
     if (more) commit_a(s + 1, buf ^ 1);
     __syncthreads();
+  };
+  for (int s = slab_begin; s < slab_end; s += 2) {
+    step(s, rawA);
+    if (s + 1 < slab_end) step(s + 1, rawB);
   }
   // ---- store: acc[m][i][r] = dW[o = 16*(og*mo+m) + 4*kb + r][c = cch[i]] ----
   float* dst = p.partial + (long long)range * p.Cout * p.Cin;
@@ -771,10 +853,10 @@ void p1_wgrad_plan(P1Wgrad* p) {
   p->nranges = (int)((slabs + per - 1) / per);
 }
 
-template <int NP, int DT>
-static int p1_wgrad_launch_t(const P1Wgrad& p, hipStream_t s) {
+template <int NP, int DT, bool V4>
+static int p1_wgrad_launch_v(const P1Wgrad& p, hipStream_t s) {
   const size_t lds = (size_t)2 * 2 * 8 * NP * 1024;
-  auto kern = p1_wgrad_k<NP, DT>;
+  auto kern = p1_wgrad_k<NP, DT, V4>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -784,6 +866,15 @@ static int p1_wgrad_launch_t(const P1Wgrad& p, hipStream_t s) {
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(p.nranges * p.ogroups * p.cblocks)), dim3(256), lds, s, p);
   return (int)hipGetLastError();
+}
+
+template <int NP, int DT>
+static int p1_wgrad_launch_t(const P1Wgrad& p, hipStream_t s) {
+  const int PW = p.W / 2, PP = (p.H / 2) * PW;
+  const bool v4 = (PW % 2) == 0 && (PP % 2) == 0 && PP >= 2 && (p.ns % 4) == 0 && (p.cs % 4) == 0 &&
+                  (reinterpret_cast<uintptr_t>(p.S) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.dYp) & 7) == 0 &&
+                  (reinterpret_cast<uintptr_t>(p.pool_idx) & 1) == 0;
+  return v4 ? p1_wgrad_launch_v<NP, DT, true>(p, s) : p1_wgrad_launch_v<NP, DT, false>(p, s);
 }
 
 int p1_wgrad_launch(const P1Wgrad& p, int np, int dt, hipStream_t s) {
