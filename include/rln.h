@@ -179,6 +179,12 @@ int rln_op_td_fwd(const float* x, int n, int cin, int x_ctot, int x_coff, int h,
                   const float* weight, const float* bias, int cout, const float* scale, float* out, int out_ctot,
                   int out_coff, uint8_t* pool_idx, float* stats, int parts, int dtype, void* workspace,
                   size_t workspace_bytes, void* stream);
+/* rln_op_tu_fwd: the TransitionUp forward (ConvTranspose2d k3 s2 + bias, top-left crop to (hout, wout)) on the 16-bit
+ * MFMA pipe with split fp32 operands (csrc/ct3.h); x is a channel range [x_coff, x_coff + cin) of a [N, x_ctot, H, W]
+ * tensor, stats optional [cout, 2] sums of what was written; parts / dtype as rln_op_dense3_fwd. */
+int rln_op_tu_fwd(const float* x, int n, int cin, int x_ctot, int x_coff, int h, int w, const float* weight,
+                  const float* bias, int cout, float* out, int out_ctot, int out_coff, int hout, int wout, float* stats,
+                  int parts, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 /* rln_op_convt: ConvTranspose2d(k3,s2,p0)+bias cropped top-left to (hout,wout) (layers.py:58-67,82-86). */
 int rln_op_convt(const float* x, int n, int cin, int h, int w, const float* weight, const float* bias, int cout,
                  float* out, int out_ctot, int out_coff, int hout, int wout, void* stream);

@@ -22,6 +22,7 @@
 #include "../../include/rln.h"
 #include "dense3.h"
 #include "pw1.h"
+#include "ct3.h"
 #include "igemm.h"
 #include "pointwise.h"
 
@@ -176,6 +177,11 @@ struct rln_ctx {
   P1PackDesc* p1_desc_f_dev = nullptr;
   P1PackDesc* p1_desc_b_dev = nullptr;
   int p1_units_f = 0, p1_units_b = 0;
+  std::vector<C3PackDesc> c3_desc_f, c3_desc_b;  // TransitionUp 3x3 transposed-conv weights (same packed buffer)
+  std::vector<long long> c3_wf_off, c3_wb_off;
+  C3PackDesc* c3_desc_f_dev = nullptr;
+  C3PackDesc* c3_desc_b_dev = nullptr;
+  int c3_units_f = 0, c3_units_b = 0;
   std::vector<float*> dyblk;  // one finalised-output-gradient buffer per layer of a dense block (pull-form backward)
 };
 
@@ -555,6 +561,7 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
       igemm_tile_dims(IG_CONV3_RAW, tile, &th, &tw);
       const size_t blocks = (size_t)n * 4 * ((GHc + th - 1) / th) * ((GWc + tw - 1) / tw);
       stat_max = std::max(stat_max, blocks * o.cout * 2);
+      if (c->d3_fwd_np > 0) stat_max = std::max(stat_max, (size_t)256 * o.cout * 2);
       if (with_bwd) {
         const int Hs = hs[o.src_level], Ws = ws[o.src_level];
         dy_max = std::max(dy_max, (size_t)n * o.cout * Hd * Wd);
@@ -644,6 +651,37 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
       pbh.push_back(d);
     }
   }
+  std::vector<C3PackDesc> cfh, cbh;
+  std::vector<long long> c3f_off(c->ops.size(), -1), c3b_off(c->ops.size(), -1);
+  int cu_f = 0, cu_b = 0;
+  for (size_t k = 0; k < c->ops.size(); ++k) {
+    const Op& o = c->ops[k];
+    if (o.type != OP_TU) continue;
+    C3PackDesc d;
+    d.w_off = o.conv.w;
+    d.cin = o.cin;
+    d.cout = o.cout;
+    if (c->d3_fwd_np > 0) {
+      d.wf_off = pk_total;
+      d.wb_off = -1;
+      d.unit_begin = cu_f;
+      d.n_units = c3_units_f(o.cin, o.cout);
+      c3f_off[k] = pk_total;
+      pk_total += (long long)d.n_units * c->d3_fwd_np * 64;
+      cu_f += d.n_units;
+      cfh.push_back(d);
+    }
+    if (c->d3_bwd_np > 0 && with_bwd) {
+      d.wf_off = -1;
+      d.wb_off = pk_total;
+      d.unit_begin = cu_b;
+      d.n_units = c3_units_b(o.cin, o.cout);
+      c3b_off[k] = pk_total;
+      pk_total += (long long)d.n_units * c->d3_bwd_np * 64;
+      cu_b += d.n_units;
+      cbh.push_back(d);
+    }
+  }
   // pull-form data gradient: the dY of every layer of a block stays alive until the block's input channels are done
   int max_block_layers = 0;
   size_t dy_dense_max = 0;
@@ -666,6 +704,8 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
   D3PackDesc* d3_db = cv.take<D3PackDesc>(dbh.size());
   P1PackDesc* p1_df = cv.take<P1PackDesc>(pfh.size());
   P1PackDesc* p1_db = cv.take<P1PackDesc>(pbh.size());
+  C3PackDesc* c3_df = cv.take<C3PackDesc>(cfh.size());
+  C3PackDesc* c3_db = cv.take<C3PackDesc>(cbh.size());
   int* lcounts = cv.take<int>(32 + 256);
   float* lpartial = cv.take<float>((size_t)loss_blocks((long long)n * hw0) * 4);
   float* lresult = cv.take<float>(64);
@@ -712,6 +752,14 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
     c->p1_desc_b_dev = p1_db;
     c->p1_units_f = pu_f;
     c->p1_units_b = pu_b;
+    c->c3_desc_f = cfh;
+    c->c3_desc_b = cbh;
+    c->c3_wf_off = c3f_off;
+    c->c3_wb_off = c3b_off;
+    c->c3_desc_f_dev = c3_df;
+    c->c3_desc_b_dev = c3_db;
+    c->c3_units_f = cu_f;
+    c->c3_units_b = cu_b;
     c->loss.counts = lcounts;
     c->loss.partial = lpartial;
     c->loss.result = lresult;
@@ -909,6 +957,38 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
       if (training)
         RLN_TRY(finalize_stats(c, o.dst_level, o.out_off, o.cout, (long long)N * q.tiles_x * q.tiles_y, s,
                                (long long)k));
+      return 0;
+    }
+  }
+  if (o.type == OP_TU && c->d3_fwd_np > 0 && c->c3_wf_off[k] >= 0) {  // split-operand 16-bit MFMA kernel (ct3.h)
+    const Level& sl = c->levels[o.src_level];
+    C3Fwd q;
+    memset(&q, 0, sizeof(q));
+    q.X = p.in;
+    q.ns = p.in_ns;
+    q.cs = p.in_cs;
+    q.H = sl.H;
+    q.W = sl.W;
+    q.Cin = o.cin;
+    q.N = N;
+    q.wpk = c->d3_packed + c->c3_wf_off[k];
+    q.bias = p.bias;
+    q.out = p.out;
+    q.out_ns = p.out_ns;
+    q.out_cs = p.out_cs;
+    q.Cout = o.cout;
+    q.Ho = dl.H;
+    q.Wo = dl.W;
+    q.stat_partial = p.stat_partial;
+    if (c3_fwd_supported(q)) {
+      c3_fwd_plan(&q, c->d3_fwd_np);
+      {
+        const double flops = 2.0 * o.cin * o.cout * 9.0 * sl.H * sl.W * N;
+        const double bytes = 4.0 * N * ((double)o.cin * sl.H * sl.W + (double)o.cout * dl.H * dl.W);
+        ProfScope ps(c, PC_TU_FWD, flops, bytes, s);
+        RLN_TRY(c3_fwd_launch(q, c->d3_fwd_np, c->d3_fwd_dt, s));
+      }
+      if (training) RLN_TRY(finalize_stats(c, o.dst_level, o.out_off, o.cout, (long long)q.bpg, s, (long long)k));
       return 0;
     }
   }
@@ -1794,6 +1874,16 @@ int rln_set_workspace(rln_ctx* c, void* ws, size_t bytes, int n, int h, int w, i
                     hipMemcpyHostToDevice);
     if (e != hipSuccess) return fail((int)e, "descriptor upload failed");
   }
+  if (!c->c3_desc_f.empty() || !c->c3_desc_b.empty()) {
+    hipError_t e = hipSuccess;
+    if (!c->c3_desc_f.empty())
+      e = hipMemcpy(c->c3_desc_f_dev, c->c3_desc_f.data(), c->c3_desc_f.size() * sizeof(C3PackDesc),
+                    hipMemcpyHostToDevice);
+    if (e == hipSuccess && !c->c3_desc_b.empty())
+      e = hipMemcpy(c->c3_desc_b_dev, c->c3_desc_b.data(), c->c3_desc_b.size() * sizeof(C3PackDesc),
+                    hipMemcpyHostToDevice);
+    if (e != hipSuccess) return fail((int)e, "descriptor upload failed");
+  }
   if (!c->p1_desc_f.empty() || !c->p1_desc_b.empty()) {
     hipError_t e = hipSuccess;
     if (!c->p1_desc_f.empty())
@@ -1836,6 +1926,12 @@ int rln_forward(rln_ctx* c, const float* x, int n, int h, int w, int training, c
                             c->d3_fwd_np, c->d3_fwd_dt, s));
   if (c->d3_units_b > 0 && training && c->with_bwd)
     RLN_TRY(d3_pack_weights(c->params, c->d3_desc_b_dev, (int)c->d3_desc_b.size(), c->d3_units_b, c->d3_packed,
+                            c->d3_bwd_np, c->d3_bwd_dt, s));
+  if (c->c3_units_f > 0)
+    RLN_TRY(c3_pack_weights(c->params, c->c3_desc_f_dev, (int)c->c3_desc_f.size(), c->c3_units_f, c->d3_packed,
+                            c->d3_fwd_np, c->d3_fwd_dt, s));
+  if (c->c3_units_b > 0 && training && c->with_bwd)
+    RLN_TRY(c3_pack_weights(c->params, c->c3_desc_b_dev, (int)c->c3_desc_b.size(), c->c3_units_b, c->d3_packed,
                             c->d3_bwd_np, c->d3_bwd_dt, s));
   if (c->p1_units_f > 0)
     RLN_TRY(p1_pack_weights(c->params, c->p1_desc_f_dev, (int)c->p1_desc_f.size(), c->p1_units_f, c->d3_packed,
@@ -2110,6 +2206,57 @@ int rln_op_td_fwd(const float* x, int n, int cin, int x_ctot, int x_coff, int h,
   if (rln_env("RLN_P1_DBG")) p.dbg = atoi(rln_env("RLN_P1_DBG"));
 #endif
   RLN_TRY(p1_fwd_launch(p, parts, dtype, s));
+  if (stats) RLN_TRY(reduce_rows(partial, p.bpg, (long long)cout * 2, stats, s));
+  return 0;
+}
+
+int rln_op_tu_fwd(const float* x, int n, int cin, int x_ctot, int x_coff, int h, int w, const float* weight,
+                  const float* bias, int cout, float* out, int out_ctot, int out_coff, int hout, int wout, float* stats,
+                  int parts, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!x || !weight || !out || !workspace) return fail(RLN_ERR_ARG, "null pointer");
+  if (parts < 1 || parts > 3 || dtype < 0 || dtype > 1 || (dtype == 1 && parts == 3))
+    return fail(RLN_ERR_ARG, "parts in 1..3 (f16: 1..2), dtype 0 (bf16) or 1 (f16)");
+  if (hout > 2 * h + 1 || wout > 2 * w + 1) return fail(RLN_ERR_ARG, "crop larger than the transposed conv output");
+  const size_t plane = (size_t)h * w, oplane = (size_t)hout * wout;
+  C3Fwd p;
+  memset(&p, 0, sizeof(p));
+  p.X = x + (size_t)x_coff * plane;
+  p.ns = (long long)x_ctot * plane;
+  p.cs = (int)plane;
+  p.H = h;
+  p.W = w;
+  p.Cin = cin;
+  p.N = n;
+  p.bias = bias;
+  p.out = out + (size_t)out_coff * oplane;
+  p.out_ns = (long long)out_ctot * oplane;
+  p.out_cs = (int)oplane;
+  p.Cout = cout;
+  p.Ho = hout;
+  p.Wo = wout;
+  if (!c3_fwd_supported(p)) return fail(RLN_ERR_UNSUPPORTED, "geometry not covered by the transposed-conv forward kernel");
+  c3_fwd_plan(&p, parts);
+  Carver cv(workspace);
+  C3PackDesc* desc = cv.take<C3PackDesc>(1);
+  uint4* packed = cv.take<uint4>((size_t)c3_units_f(cin, cout) * parts * 64);
+  float* partial = stats ? cv.take<float>((size_t)p.bpg * cout * 2) : nullptr;
+  if (cv.off > workspace_bytes) return fail(RLN_ERR_WORKSPACE, "workspace of %zu bytes needed", cv.off);
+  C3PackDesc d;
+  d.w_off = 0;
+  d.cin = cin;
+  d.cout = cout;
+  d.wf_off = 0;
+  d.wb_off = -1;
+  d.unit_begin = 0;
+  d.n_units = c3_units_f(cin, cout);
+  hipError_t e = hipMemcpyAsync(desc, &d, sizeof(d), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);  // `d` is a stack object
+  if (e != hipSuccess) return fail((int)e, "descriptor upload failed");
+  RLN_TRY(c3_pack_weights(weight, desc, 1, d.n_units, packed, parts, dtype, s));
+  p.wpk = packed;
+  p.stat_partial = partial;
+  RLN_TRY(c3_fwd_launch(p, parts, dtype, s));
   if (stats) RLN_TRY(reduce_rows(partial, p.bpg, (long long)cout * 2, stats, s));
   return 0;
 }
