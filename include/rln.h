@@ -185,6 +185,12 @@ int rln_op_td_fwd(const float* x, int n, int cin, int x_ctot, int x_coff, int h,
 int rln_op_tu_fwd(const float* x, int n, int cin, int x_ctot, int x_coff, int h, int w, const float* weight,
                   const float* bias, int cout, float* out, int out_ctot, int out_coff, int hout, int wout, float* stats,
                   int parts, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+/* rln_op_tu_bwd: backward of the same transposed convolution on the split-operand kernels: dx[N, cin, h, w] =
+ * cscale[c] * d(out)/d(x) . du (overwritten; cscale may be NULL) and dw[cin, cout, 3, 3]; either output may be NULL.
+ * x and du are contiguous.  The weight-gradient kernel needs w % 8 == 0, both need wout == 2 w. */
+int rln_op_tu_bwd(const float* x, const float* du, const float* weight, int n, int cin, int cout, int h, int w, int hout,
+                  int wout, const float* cscale, float* dx, float* dw, int parts, int dtype, void* workspace,
+                  size_t workspace_bytes, void* stream);
 /* rln_op_convt: ConvTranspose2d(k3,s2,p0)+bias cropped top-left to (hout,wout) (layers.py:58-67,82-86). */
 int rln_op_convt(const float* x, int n, int cin, int h, int w, const float* weight, const float* bias, int cout,
                  float* out, int out_ctot, int out_coff, int hout, int wout, void* stream);

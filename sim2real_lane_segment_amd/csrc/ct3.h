@@ -19,15 +19,26 @@ namespace rln {
 
 // ---- weight packing: W[cin][cout][3][3] --------------------------------------------------------------------------------
 //   forward  wf[mtile][kstep][tap][part][lane]: lane (i = l&15, kb = l>>4) holds W[c = 32*kstep + 8*kb + e][o = 16*mtile + i][tap]
-//   backward wb[mtile][kstep][tap][part][lane]: lane (i, kb) holds W[c = 16*mtile + i][o = 32*kstep + 8*kb + e][tap]
+//   backward wb[group][kstep][ky][m][kx][part][lane] (mtile = group * c3_dgrad_mt + m): lane (i, kb) holds
+//            W[c = 16*mtile + i][o = 32*kstep + 8*kb + e][3*ky + kx]
 struct C3PackDesc {
   long long w_off;
   int cin, cout;
   long long wf_off, wb_off;  // uint4 units into the packed buffer; -1: skip
   int unit_begin, n_units;   // units = (mtile, kstep, tap) triples, forward first
 };
+// M tiles (16 input channels each) per block of the data-gradient kernel: balanced groups of at most 5
+__host__ __device__ inline int c3_dgrad_mt(int m_tiles) {
+  const int groups = (m_tiles + 4) / 5;
+  return (m_tiles + groups - 1) / groups;
+}
 inline int c3_units_f(int cin, int cout) { return ((cout + 15) / 16) * ((cin + 31) / 32) * 9; }
 inline int c3_units_b(int cin, int cout) { return ((cin + 15) / 16) * ((cout + 31) / 32) * 9; }
+// uint4 entries of the backward fragment buffer (groups are padded to c3_dgrad_mt tiles)
+inline long long c3_entries_b(int cin, int cout, int np) {
+  const int MT = (cin + 15) / 16, mtb = c3_dgrad_mt(MT), groups = (MT + mtb - 1) / mtb;
+  return (long long)groups * mtb * ((cout + 31) / 32) * 9 * np * 64;
+}
 int c3_pack_weights(const float* params, const C3PackDesc* desc_dev, int n_desc, int total_units, uint4* packed, int np,
                     int dt, hipStream_t s);
 
@@ -57,10 +68,10 @@ struct C3Dgrad {
   float* G;              // output view [N][.][H][W]
   long long ns;
   int cs, H, W, C, N;
-  int mt, groups, bpg;
+  int mt, groups, bpg;  // mt = c3_dgrad_mt(ceil(C/16))
 };
 bool c3_dgrad_supported(const C3Dgrad& p);
-void c3_dgrad_plan(C3Dgrad* p, int np);
+void c3_dgrad_plan(C3Dgrad* p);
 int c3_dgrad_launch(const C3Dgrad& p, int np, int dt, hipStream_t s);
 
 // ---- weight gradient: dW[c][o][ky][kx] = sum_{n,y,x} X[n][c][y][x] * dU[n][o][2y+ky][2x+kx] -------------------------------
@@ -71,8 +82,8 @@ struct C3Wgrad {
   const float* dU;
   int Cout, Ho, Wo;
   float* partial;  // [nranges][Cin][Cout][9]
-  int mo, nc;      // output-channel tiles (<= 5) and input-channel tiles (<= 5) per block
-  int ogroups, cgroups, nranges, per;
+  int mo, nc;      // output-channel tiles (<= 2: the block has 3*mo waves) and input-channel tiles (<= 5) per block
+  int ogroups, cgroups, nranges, per;  // per = K steps (32 input pixels) per range
 };
 bool c3_wgrad_supported(const C3Wgrad& p);
 void c3_wgrad_plan(C3Wgrad* p);

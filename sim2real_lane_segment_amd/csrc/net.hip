@@ -571,6 +571,17 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
         const long long items = (long long)n * ((Hs + wth - 1) / wth) * ((Ws + wtw - 1) / wtw);
         const long long nch = wgrad_chunks(items, (o.cout + 15) / 16, (o.cin + 63) / 64, &ipc);
         wp_max = std::max(wp_max, (size_t)nch * o.cout * o.cin * 9);
+        if (c->d3_bwd_np > 0 && (Ws % 8) == 0 && Ws >= 8) {
+          C3Wgrad g;
+          memset(&g, 0, sizeof(g));
+          g.Cout = o.cout;
+          g.Cin = o.cin;
+          g.H = Hs;
+          g.W = Ws;
+          g.N = n;
+          c3_wgrad_plan(&g);
+          wp_max = std::max(wp_max, (size_t)g.nranges * o.cout * o.cin * 9);
+        }
       }
     }
   }
@@ -677,7 +688,7 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
       d.unit_begin = cu_b;
       d.n_units = c3_units_b(o.cin, o.cout);
       c3b_off[k] = pk_total;
-      pk_total += (long long)d.n_units * c->d3_bwd_np * 64;
+      pk_total += c3_entries_b(o.cin, o.cout, c->d3_bwd_np);
       cu_b += d.n_units;
       cbh.push_back(d);
     }
@@ -1535,11 +1546,70 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
     p.tiles_y = (p.GH + th - 1) / th;
     p.tiles_x = (p.GW + tw - 1) / tw;
     p.out_vec = ((sl.W % 4) == 0 && aligned16(p.out)) ? 1 : 0;
-    {
+    bool dgrad_done = false;
+    if (c->d3_bwd_np > 0 && c->c3_wb_off[k] >= 0) {  // split-operand 16-bit MFMA kernel (ct3.h)
+      C3Dgrad q;
+      memset(&q, 0, sizeof(q));
+      q.dU = c->dY;
+      q.Cout = o.cout;
+      q.Ho = dl.H;
+      q.Wo = dl.W;
+      q.wpk = c->d3_packed + c->c3_wb_off[k];
+      q.cscale = p.cscale;
+      q.G = p.out;
+      q.ns = p.out_ns;
+      q.cs = p.out_cs;
+      q.H = sl.H;
+      q.W = sl.W;
+      q.C = o.cin;
+      q.N = N;
+      if (c3_dgrad_supported(q)) {
+        c3_dgrad_plan(&q);
+        const double flops = 2.0 * o.cin * o.cout * 9.0 * splane * N;
+        const double bytes = 4.0 * N * ((double)o.cout * dplane + (double)o.cin * splane);
+        ProfScope ps(c, PC_TU_DGRAD, flops, bytes, s);
+        RLN_TRY(c3_dgrad_launch(q, c->d3_bwd_np, c->d3_bwd_dt, s));
+        dgrad_done = true;
+      }
+    }
+    if (!dgrad_done) {
       const double flops = 2.0 * o.cin * o.cout * 9.0 * splane * N;
       const double bytes = 4.0 * N * ((double)o.cout * dplane + (double)o.cin * splane);
       ProfScope ps(c, PC_TU_DGRAD, flops, bytes, s);
       RLN_TRY(igemm_launch(IG_S2D3, tile, p, N, s));
+    }
+    if (c->d3_bwd_np > 0) {
+      C3Wgrad g;
+      memset(&g, 0, sizeof(g));
+      g.X = sl.S + (size_t)o.in_off * splane;
+      g.ns = (long long)sl.C * splane;
+      g.cs = (int)splane;
+      g.H = sl.H;
+      g.W = sl.W;
+      g.Cin = o.cin;
+      g.N = N;
+      g.dU = c->dY;
+      g.Cout = o.cout;
+      g.Ho = dl.H;
+      g.Wo = dl.W;
+      g.partial = c->wpartial;
+      if (c3_wgrad_supported(g)) {
+        c3_wgrad_plan(&g);
+        RLN_TRY(wg_begin(c, s, &ws));
+        {
+          const double flops = 2.0 * o.cin * o.cout * 9.0 * splane * N;
+          const double bytes = 4.0 * N * ((double)o.cout * dplane + (double)o.cin * splane);
+          ProfScope ps(c, PC_TU_WGRAD, flops, bytes, ws);
+          RLN_TRY(c3_wgrad_launch(g, c->d3_bwd_np, c->d3_bwd_dt, ws));
+        }
+        {
+          const long long wsize = (long long)o.cin * o.cout * 9;
+          ProfScope ps2(c, PC_REDUCE, 0, 4.0 * (g.nranges + 1) * wsize, ws);
+          RLN_TRY(reduce_rows(c->wpartial, g.nranges, wsize, c->grads + o.conv.w, ws));
+        }
+        RLN_TRY(wg_end(c));
+        return 0;
+      }
     }
     WgradParams w;
     memset(&w, 0, sizeof(w));
@@ -2258,6 +2328,74 @@ int rln_op_tu_fwd(const float* x, int n, int cin, int x_ctot, int x_coff, int h,
   p.stat_partial = partial;
   RLN_TRY(c3_fwd_launch(p, parts, dtype, s));
   if (stats) RLN_TRY(reduce_rows(partial, p.bpg, (long long)cout * 2, stats, s));
+  return 0;
+}
+
+int rln_op_tu_bwd(const float* x, const float* du, const float* weight, int n, int cin, int cout, int h, int w, int hout,
+                  int wout, const float* cscale, float* dx, float* dw, int parts, int dtype, void* workspace,
+                  size_t workspace_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!x || !du || !weight || !workspace || (!dx && !dw)) return fail(RLN_ERR_ARG, "null pointer");
+  if (parts < 1 || parts > 3 || dtype < 0 || dtype > 1 || (dtype == 1 && parts == 3))
+    return fail(RLN_ERR_ARG, "parts in 1..3 (f16: 1..2), dtype 0 (bf16) or 1 (f16)");
+  const size_t plane = (size_t)h * w;
+  C3Dgrad q;
+  memset(&q, 0, sizeof(q));
+  q.dU = du;
+  q.Cout = cout;
+  q.Ho = hout;
+  q.Wo = wout;
+  q.cscale = cscale;
+  q.G = dx;
+  q.ns = (long long)cin * plane;
+  q.cs = (int)plane;
+  q.H = h;
+  q.W = w;
+  q.C = cin;
+  q.N = n;
+  C3Wgrad g;
+  memset(&g, 0, sizeof(g));
+  g.X = x;
+  g.ns = q.ns;
+  g.cs = q.cs;
+  g.H = h;
+  g.W = w;
+  g.Cin = cin;
+  g.N = n;
+  g.dU = du;
+  g.Cout = cout;
+  g.Ho = hout;
+  g.Wo = wout;
+  if ((dx && !c3_dgrad_supported(q)) || (dw && !c3_wgrad_supported(g)))
+    return fail(RLN_ERR_UNSUPPORTED, "geometry not covered by the transposed-conv backward kernels");
+  c3_dgrad_plan(&q);
+  if (dw) c3_wgrad_plan(&g);
+  Carver cv(workspace);
+  C3PackDesc* desc = cv.take<C3PackDesc>(1);
+  uint4* packed = cv.take<uint4>((size_t)c3_entries_b(cin, cout, parts));
+  float* partial = cv.take<float>(dw ? (size_t)g.nranges * cin * cout * 9 : 0);
+  if (cv.off > workspace_bytes) return fail(RLN_ERR_WORKSPACE, "workspace of %zu bytes needed", cv.off);
+  if (dx) {
+    C3PackDesc d;
+    d.w_off = 0;
+    d.cin = cin;
+    d.cout = cout;
+    d.wf_off = -1;
+    d.wb_off = 0;
+    d.unit_begin = 0;
+    d.n_units = c3_units_b(cin, cout);
+    hipError_t e = hipMemcpyAsync(desc, &d, sizeof(d), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);  // `d` is a stack object
+    if (e != hipSuccess) return fail((int)e, "descriptor upload failed");
+    RLN_TRY(c3_pack_weights(weight, desc, 1, d.n_units, packed, parts, dtype, s));
+    q.wpk = packed;
+    RLN_TRY(c3_dgrad_launch(q, parts, dtype, s));
+  }
+  if (dw) {
+    g.partial = partial;
+    RLN_TRY(c3_wgrad_launch(g, parts, dtype, s));
+    RLN_TRY(reduce_rows(partial, g.nranges, (long long)cin * cout * 9, dw, s));
+  }
   return 0;
 }
 
