@@ -604,8 +604,8 @@ int c3_dgrad_launch(const C3Dgrad& p, int np, int dt, hipStream_t s) {
 // partial[range][c][o][ky][kx] is reduced afterwards in fixed order.
 // =============================================================================================
 constexpr int C3_WNC = 5;
-template <int NP, int DT>
-__global__ __launch_bounds__(384, 3) void c3_wgrad_k(const C3Wgrad p) {
+template <int NP, int DT, int MO>
+__global__ __launch_bounds__(192 * MO, 3) void c3_wgrad_k(const C3Wgrad p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nthreads = blockDim.x;
@@ -629,33 +629,36 @@ __global__ __launch_bounds__(384, 3) void c3_wgrad_k(const C3Wgrad p) {
 
   // ---- A side ----
   const int o_lane = min(otile * 16 + n16, p.Cout - 1);
-  float4 ar[4];
-  float a16;
-  bool a_ok;
-  auto issue_a = [&](int kstep) __attribute__((always_inline)) {
+  struct ARaw {
+    float4 r[4];
+    float r16;
+    bool ok;
+  };
+  ARaw arA, arB;  // two K steps in flight
+  auto issue_a = [&](int kstep, ARaw& a) __attribute__((always_inline)) {
     const int sg = kstep * 4 + kb;
     const int sgc = min(sg, SG - 1);
     const int ns_ = sgc / (p.H * W8);
     const int rem = sgc - ns_ * (p.H * W8);
     const int y = rem / W8, x0 = (rem - y * W8) * 8;
     const int Y = 2 * y + ky;
-    a_ok = sg < SG && Y < p.Ho;
+    a.ok = sg < SG && Y < p.Ho;
     const float* q = p.dU + ((long long)ns_ * p.Cout + o_lane) * oplane + (long long)min(Y, p.Ho - 1) * p.Wo + 2 * x0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ar[i] = reinterpret_cast<const float4*>(q)[i];
-    a16 = (2 * x0 + 16 < p.Wo) ? q[16] : 0.f;
+    for (int i = 0; i < 4; ++i) a.r[i] = reinterpret_cast<const float4*>(q)[i];
+    a.r16 = (2 * x0 + 16 < p.Wo) ? q[16] : 0.f;
   };
   uint4 af[3][NP];
-  auto convert_a = [&]() __attribute__((always_inline)) {
+  auto convert_a = [&](const ARaw& a) __attribute__((always_inline)) {
     float u[17];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      u[4 * i + 0] = a_ok ? ar[i].x : 0.f;
-      u[4 * i + 1] = a_ok ? ar[i].y : 0.f;
-      u[4 * i + 2] = a_ok ? ar[i].z : 0.f;
-      u[4 * i + 3] = a_ok ? ar[i].w : 0.f;
+      u[4 * i + 0] = a.ok ? a.r[i].x : 0.f;
+      u[4 * i + 1] = a.ok ? a.r[i].y : 0.f;
+      u[4 * i + 2] = a.ok ? a.r[i].z : 0.f;
+      u[4 * i + 3] = a.ok ? a.r[i].w : 0.f;
     }
-    u[16] = a_ok ? a16 : 0.f;
+    u[16] = a.ok ? a.r16 : 0.f;
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       unsigned w[4][NP];
@@ -667,7 +670,7 @@ __global__ __launch_bounds__(384, 3) void c3_wgrad_k(const C3Wgrad p) {
   };
 
   // ---- B side: thread t stages the float4 (channel c = t / 8, quarter q = t % 8 -> segment q / 2, half q % 2) ----
-  constexpr int BCH = 4;  // up to 4 float4 per thread (80 channels x 8 / 192 threads)
+  constexpr int BCH = MO == 2 ? 2 : 4;  // float4 per thread: 80 channels x 8 quarters over 384 / 192 threads
   float4 br[BCH];
   auto issue_b = [&](int kstep) __attribute__((always_inline)) {
 #pragma unroll
@@ -709,17 +712,18 @@ __global__ __launch_bounds__(384, 3) void c3_wgrad_k(const C3Wgrad p) {
 
   if (k_begin < k_end) {
     issue_b(k_begin);
-    issue_a(k_begin);
+    issue_a(k_begin, arA);
+    if (k_begin + 1 < k_end) issue_a(k_begin + 1, arB);
     commit_b(k_begin, 0);
   }
   __syncthreads();
-  for (int k = k_begin; k < k_end; ++k) {
+  auto step = [&](int k, ARaw& a) __attribute__((always_inline)) {
     const int buf = (k - k_begin) & 1;
     const bool more = k + 1 < k_end;
     if (more) issue_b(k + 1);
-    convert_a();
+    convert_a(a);
     __builtin_amdgcn_sched_barrier(0);
-    if (more) issue_a(k + 1);
+    if (k + 2 < k_end) issue_a(k + 2, a);
     __builtin_amdgcn_sched_barrier(0);
     if (wave_active) {
 #pragma unroll
@@ -735,6 +739,10 @@ __global__ __launch_bounds__(384, 3) void c3_wgrad_k(const C3Wgrad p) {
     }
     if (more) commit_b(k + 1, buf ^ 1);
     __syncthreads();
+  };
+  for (int k = k_begin; k < k_end; k += 2) {
+    step(k, arA);
+    if (k + 1 < k_end) step(k + 1, arB);
   }
   // ---- store: acc[kx][j][r] = dW[c = 16*(cg*nc+j) + n16][o = 16*otile + 4*kb + r][ky][kx] ----
   if (wave_active) {
@@ -775,7 +783,7 @@ void c3_wgrad_plan(C3Wgrad* p) {
   p->nc = (NT + p->cgroups - 1) / p->cgroups;
   const long long ksteps = std::max(1ll, ((long long)p->N * p->H * (p->W / 8) + 3) / 4);
   long long nr = std::max(1ll, std::min(ksteps, (long long)std::max(1, 768 / (p->ogroups * p->cgroups))));
-  nr = std::min(nr, 128ll);
+  nr = std::min(nr, 256ll);
   const long long per = (ksteps + nr - 1) / nr;
   p->per = (int)per;
   p->nranges = (int)((ksteps + per - 1) / per);
@@ -784,9 +792,10 @@ void c3_wgrad_plan(C3Wgrad* p) {
 template <int NP, int DT>
 static int c3_wgrad_launch_t(const C3Wgrad& p, hipStream_t s) {
   const size_t lds = (size_t)2 * p.nc * NP * 1024;
-  const int threads = 3 * p.mo * 64;
-  if (p.nc * 16 * 8 > 4 * threads) return -4;  // staging budget: 4 float4 per thread
-  hipLaunchKernelGGL((c3_wgrad_k<NP, DT>), dim3((unsigned)(p.nranges * p.ogroups * p.cgroups)), dim3(threads), lds, s, p);
+  const dim3 grid((unsigned)(p.nranges * p.ogroups * p.cgroups));
+  if (p.nc * 16 * 8 > 768) return -4;  // staging budget of the block's threads
+  if (p.mo == 2) hipLaunchKernelGGL((c3_wgrad_k<NP, DT, 2>), grid, dim3(384), lds, s, p);
+  else hipLaunchKernelGGL((c3_wgrad_k<NP, DT, 1>), grid, dim3(192), lds, s, p);
   return (int)hipGetLastError();
 }
 
