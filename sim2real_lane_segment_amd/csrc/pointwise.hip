@@ -809,7 +809,9 @@ __global__ __launch_bounds__(256) void head_bwd_fused_k(const HeadBwdParams q, f
   float* red = bt + NC;                             // [8][1 + NC][32]
   float* gls = red + 8 * (1 + NC) * HEAD_TPX;       // [NC][32]   glin = gl * inv
   float* xs = gls + NC * HEAD_TPX;                  // [C][HEAD_XS]
+  float* sdt = xs + (long long)p.C * HEAD_XS;       // [C] 1 / invstd (a multiply per element instead of a divide)
   load_head_weights<NC>(wt, bt, p);
+  for (int e = threadIdx.x; e < p.C; e += 256) sdt[e] = 1.f / q.invstd[e];
   const int tid = threadIdx.x, pl = tid & 31, g = tid >> 5;
   const int n = blockIdx.y;
   const float* Sn = p.S + (long long)n * p.ns;
@@ -907,7 +909,7 @@ __global__ __launch_bounds__(256) void head_bwd_fused_k(const HeadBwdParams q, f
 #pragma unroll
       for (int k = 0; k < NC; ++k) gxn = fmaf(wt[c * NC + k], gl[k], gxn);
       const float gx = q.feat_sign * (gxn - x * inv * t) * inv;
-      if (active) Gn[(long long)c * p.HW + px] = gx / q.invstd[c];
+      if (active) Gn[(long long)c * p.HW + px] = gx * sdt[c];
     }
     __syncthreads();  // gls visible
     // ---- (3) classifier weight gradient: thread-owned channels tid and tid + 256 ----
@@ -955,7 +957,9 @@ int head_backward_fused(const HeadBwdParams& q, int N, float* wpartial, long lon
   const int ntile = (p.HW + HEAD_TPX - 1) / HEAD_TPX;
   dim3 grid((unsigned)((ntile + HEAD_TPB - 1) / HEAD_TPB), (unsigned)N);
   if (rows) *rows = (long long)grid.x * N;
-  auto lds = [&](int nc) { return (size_t)(p.C * nc + nc + 8 * (1 + nc) * HEAD_TPX + nc * HEAD_TPX + p.C * HEAD_XS) * 4; };
+  auto lds = [&](int nc) {
+    return (size_t)(p.C * nc + nc + 8 * (1 + nc) * HEAD_TPX + nc * HEAD_TPX + p.C * HEAD_XS + p.C) * 4;
+  };
 #define RLN_HEAD_FUSED(NCV)                                                                                         \
   {                                                                                                                 \
     static bool attr = false;                                                                                       \
