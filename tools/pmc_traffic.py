@@ -17,6 +17,8 @@ import sys
 
 WIDE_READ_KERNELS = ("d3_fwd_k", "d3_pull_k", "d3_wgrad_k", "dgrad_loop_k", "igemm_k<3, 1, 1, 0, 4, 160", "igemm_k<3, 1, 1, 0, 8, 80",
                      "igemm_k<3, 1, 1, 0, 4, 80", "wgrad_dense_q_k", "grad_finalize_k", "adamw_k", "reduce_rows")
+# the transition kernels (p1_*, c3_*) gather 4..16 B per lane in 64-byte runs, not wide coalesced streams: reported
+# uncorrected (uncalibrated width, stated as such in the summary)
 
 
 def load(d, counter):
