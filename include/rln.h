@@ -179,6 +179,14 @@ int rln_op_td_fwd(const float* x, int n, int cin, int x_ctot, int x_coff, int h,
                   const float* weight, const float* bias, int cout, const float* scale, float* out, int out_ctot,
                   int out_coff, uint8_t* pool_idx, float* stats, int parts, int dtype, void* workspace,
                   size_t workspace_bytes, void* stream);
+/* rln_op_td_bwd: backward of that transition on the split-operand kernels.  dyp [N, cout, h/2, w/2] is the gradient of
+ * the pooled output (Dropout2d scale already applied), pool_idx the forward's argmax bytes; x [N, cin, h, w] contiguous.
+ * g (optional): channels in [acc_lo, acc_hi) accumulate gamma[c] * gz, the others are overwritten, gz = relu'(a x + b) *
+ * (W^T unpool(dyp)); stats (optional) [cin, 2] = sum gz, sum gz * (x - mean) * invstd.  dw (optional) [cout, cin]. */
+int rln_op_td_bwd(const float* x, const float* dyp, const uint8_t* pool_idx, const float* weight, int n, int cin, int cout,
+                  int h, int w, const float* a, const float* b, const float* gamma, const float* mean, const float* invstd,
+                  int acc_lo, int acc_hi, float* g, float* stats, float* dw, int parts, int dtype, void* workspace,
+                  size_t workspace_bytes, void* stream);
 /* rln_op_tu_fwd: the TransitionUp forward (ConvTranspose2d k3 s2 + bias, top-left crop to (hout, wout)) on the 16-bit
  * MFMA pipe with split fp32 operands (csrc/ct3.h); x is a channel range [x_coff, x_coff + cin) of a [N, x_ctot, H, W]
  * tensor, stats optional [cout, 2] sums of what was written; parts / dtype as rln_op_dense3_fwd. */

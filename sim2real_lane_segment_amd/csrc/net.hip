@@ -2399,6 +2399,86 @@ int rln_op_tu_bwd(const float* x, const float* du, const float* weight, int n, i
   return 0;
 }
 
+int rln_op_td_bwd(const float* x, const float* dyp, const uint8_t* pool_idx, const float* weight, int n, int cin, int cout,
+                  int h, int w, const float* a, const float* b, const float* gamma, const float* mean, const float* invstd,
+                  int acc_lo, int acc_hi, float* g, float* stats, float* dw, int parts, int dtype, void* workspace,
+                  size_t workspace_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!x || !dyp || !pool_idx || !weight || !a || !b || !workspace || (!g && !dw)) return fail(RLN_ERR_ARG, "null pointer");
+  if (g && (!gamma || !mean || !invstd)) return fail(RLN_ERR_ARG, "gamma / mean / invstd are required with g");
+  if (parts < 1 || parts > 3 || dtype < 0 || dtype > 1 || (dtype == 1 && parts == 3))
+    return fail(RLN_ERR_ARG, "parts in 1..3 (f16: 1..2), dtype 0 (bf16) or 1 (f16)");
+  const size_t plane = (size_t)h * w;
+  P1Dgrad q;
+  memset(&q, 0, sizeof(q));
+  q.dYp = dyp;
+  q.pool_idx = pool_idx;
+  q.Cout = cout;
+  q.ea = a;
+  q.eb = b;
+  q.egamma = gamma;
+  q.mean = mean;
+  q.invstd = invstd;
+  q.S = x;
+  q.ns = (long long)cin * plane;
+  q.cs = (int)plane;
+  q.G = g;
+  q.C = cin;
+  q.acc_lo = acc_lo;
+  q.acc_hi = acc_hi;
+  q.H = h;
+  q.W = w;
+  q.N = n;
+  P1Wgrad gw;
+  memset(&gw, 0, sizeof(gw));
+  gw.dYp = dyp;
+  gw.pool_idx = pool_idx;
+  gw.Cout = cout;
+  gw.S = x;
+  gw.ns = q.ns;
+  gw.cs = q.cs;
+  gw.H = h;
+  gw.W = w;
+  gw.N = n;
+  gw.Cin = cin;
+  gw.pa = a;
+  gw.pb = b;
+  if ((g && !p1_dgrad_supported(q)) || (dw && !p1_wgrad_supported(gw)))
+    return fail(RLN_ERR_UNSUPPORTED, "geometry not covered by the 1x1 transition backward kernels");
+  if (g) p1_dgrad_plan(&q, parts);
+  if (dw) p1_wgrad_plan(&gw);
+  Carver cv(workspace);
+  P1PackDesc* desc = cv.take<P1PackDesc>(1);
+  uint4* packed = cv.take<uint4>((size_t)p1_units_b(cin, cout) * parts * 64);
+  float* spart = (g && stats) ? cv.take<float>((size_t)q.bpg * cin * 2) : nullptr;
+  float* wpart = dw ? cv.take<float>((size_t)gw.nranges * cin * cout) : nullptr;
+  if (cv.off > workspace_bytes) return fail(RLN_ERR_WORKSPACE, "workspace of %zu bytes needed", cv.off);
+  if (g) {
+    P1PackDesc d;
+    d.w_off = 0;
+    d.cin = cin;
+    d.cout = cout;
+    d.wf_off = -1;
+    d.wb_off = 0;
+    d.unit_begin = 0;
+    d.n_units = p1_units_b(cin, cout);
+    hipError_t e = hipMemcpyAsync(desc, &d, sizeof(d), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);  // `d` is a stack object
+    if (e != hipSuccess) return fail((int)e, "descriptor upload failed");
+    RLN_TRY(p1_pack_weights(weight, desc, 1, d.n_units, packed, parts, dtype, s));
+    q.wpk = packed;
+    q.stat_partial = spart;
+    RLN_TRY(p1_dgrad_launch(q, parts, dtype, s));
+    if (stats) RLN_TRY(reduce_rows(spart, q.bpg, (long long)cin * 2, stats, s));
+  }
+  if (dw) {
+    gw.partial = wpart;
+    RLN_TRY(p1_wgrad_launch(gw, parts, dtype, s));
+    RLN_TRY(reduce_rows(wpart, gw.nranges, (long long)cin * cout, dw, s));
+  }
+  return 0;
+}
+
 int rln_op_dense3_fwd(const float* x, int n, int cin, int x_ctot, int x_coff, int h, int w, const float* a,
                       const float* b, const float* weight, const float* bias, int cout, const float* scale, float* out,
                       int out_ctot, int out_coff, float* stats, int parts, int dtype, void* workspace,

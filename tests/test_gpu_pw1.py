@@ -91,3 +91,63 @@ def test_td_forward_unsupported_geometry_is_reported():
     rc = lib.rln_op_td_fwd(_p(x), 1, 16, 16, 0, 6, 5, _p(v), _p(v), _p(v), _p(v), 16, None, _p(o), 16, 0, _p(i8), None, 2, 0,
                            _p(ws), ws.numel(), _stream())
     assert rc == -4
+
+
+BWD_CASES = [(2, 128, 128, 24, 32), (2, 208, 208, 12, 16), (3, 368, 368, 15, 20), (5, 448, 448, 7, 10), (1, 16, 24, 6, 4),
+             (3, 48, 80, 9, 14), (2, 128, 128, 120, 160)]
+
+
+@pytest.mark.parametrize("case", BWD_CASES)
+@pytest.mark.parametrize("parts,dtype", [(2, 0), (2, 1), (3, 0)])
+def test_td_backward(case, parts, dtype):
+    """Data gradient (ReLU mask, gamma scaling, accumulate / overwrite ranges, BatchNorm-backward sums) and weight gradient
+    against fp64 autograd of relu(a x + b) -> conv1x1 -> max_pool2d, with the pooled gradient and the forward's argmax
+    bytes as the kernels' inputs."""
+    n, cin, cout, h, w = case
+    if (h, w) == (120, 160) and (parts, dtype) != (2, 0):
+        pytest.skip("full-size case runs in the default backward arithmetic")
+    L, lib = _lib()
+    gen = torch.Generator().manual_seed(h * 1000 + w + cin + parts)
+    x = torch.randn(n, cin, h, w, generator=gen)
+    a = torch.rand(cin, generator=gen) + 0.5
+    b = torch.randn(cin, generator=gen) * 0.3
+    gamma = torch.rand(cin, generator=gen) + 0.5
+    mean = torch.randn(cin, generator=gen) * 0.1
+    invstd = torch.rand(cin, generator=gen) + 0.5
+    wt = torch.randn(cout, cin, generator=gen) / cin ** 0.5
+    ph, pw = h // 2, w // 2
+    dyp = torch.randn(n, cout, ph, pw, generator=gen)
+    g0 = torch.randn(n, cin, h, w, generator=gen)
+    acc_lo, acc_hi = cin // 4, cin // 2
+    # fp64 reference
+    xd = x.double()
+    z = F.relu(xd * a.double()[None, :, None, None] + b.double()[None, :, None, None]).requires_grad_()
+    wd = wt.double().requires_grad_()
+    full = F.conv2d(z, wd[:, :, None, None])
+    pooled, idx = F.max_pool2d(full, 2, return_indices=True)
+    pooled.backward(dyp.double())
+    gz = z.grad * (z > 0)
+    ref_g = gamma.double()[None, :, None, None] * gz
+    accm = torch.zeros(cin, dtype=torch.bool)
+    accm[acc_lo:acc_hi] = True
+    ref_g = ref_g + g0.double() * accm[None, :, None, None]
+    xh = (xd - mean.double()[None, :, None, None]) * invstd.double()[None, :, None, None]
+    ref_stats = torch.stack([gz.sum((0, 2, 3)), (gz * xh).sum((0, 2, 3))], 1)
+    ref_dw = wd.grad
+    iy, ix = idx // w - 2 * torch.arange(ph)[None, None, :, None], idx % w - 2 * torch.arange(pw)
+    code = (iy * 2 + ix).to(torch.uint8)
+    dev = "cuda"
+    t = lambda v: v.to(dev)
+    xg, dg, cg, wg, ag, bg, gg, mg, ig = (t(v) for v in (x, dyp, code.contiguous(), wt, a, b, gamma, mean, invstd))
+    g = g0.clone().to(dev)
+    stats = torch.zeros(cin, 2, device=dev)
+    dw = torch.full((cout, cin), 5.0, device=dev)
+    ws = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+    L.check(lib.rln_op_td_bwd(_p(xg), _p(dg), _p(cg), _p(wg), n, cin, cout, h, w, _p(ag), _p(bg), _p(gg), _p(mg), _p(ig),
+                              acc_lo, acc_hi, _p(g), _p(stats), _p(dw), parts, dtype, _p(ws), ws.numel(), _stream()))
+    torch.cuda.synchronize()
+    tol = 4 * TOL[(parts, dtype)]
+    scale_g = float((gamma.double()[None, :, None, None] * gz).abs().max())
+    assert float((g.cpu().double() - ref_g).abs().max()) / scale_g < tol
+    assert float((dw.cpu().double() - ref_dw).abs().max()) / float(ref_dw.abs().max()) < tol
+    assert float((stats.cpu().double() - ref_stats).abs().max()) / float(ref_stats.abs().max()) < tol
