@@ -187,6 +187,14 @@ int rln_op_td_bwd(const float* x, const float* dyp, const uint8_t* pool_idx, con
                   int h, int w, const float* a, const float* b, const float* gamma, const float* mean, const float* invstd,
                   int acc_lo, int acc_hi, float* g, float* stats, float* dw, int parts, int dtype, void* workspace,
                   size_t workspace_bytes, void* stream);
+/* rln_op_fc_fwd / rln_op_fc_wgrad: the first convolution (Conv2d(cin <= 3, cout <= 64, 3, padding 1) on the raw input,
+ * tiramisu.py:33-35) and its weight gradient on the split-operand kernels (csrc/fc3.h).  x [N, cin, h, w] and
+ * dy [N, cout, h, w] contiguous, dw [cout, cin, 3, 3]; w % 4 == 0 (forward), w % 8 == 0 (weight gradient). */
+int rln_op_fc_fwd(const float* x, int n, int cin, int h, int w, const float* weight, const float* bias, int cout,
+                  float* out, int out_ctot, int out_coff, float* stats, int parts, int dtype, void* workspace,
+                  size_t workspace_bytes, void* stream);
+int rln_op_fc_wgrad(const float* x, const float* dy, int n, int cin, int cout, int h, int w, float* dw, int parts, int dtype,
+                    void* workspace, size_t workspace_bytes, void* stream);
 /* rln_op_tu_fwd: the TransitionUp forward (ConvTranspose2d k3 s2 + bias, top-left crop to (hout, wout)) on the 16-bit
  * MFMA pipe with split fp32 operands (csrc/ct3.h); x is a channel range [x_coff, x_coff + cin) of a [N, x_ctot, H, W]
  * tensor, stats optional [cout, 2] sums of what was written; parts / dtype as rln_op_dense3_fwd. */

@@ -73,6 +73,10 @@ _PROTOS = {
     "rln_op_td_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                               c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                               c_void_p, c_size_t, c_void_p]),
+    "rln_op_fc_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
+                              c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "rln_op_fc_wgrad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p,
+                                c_size_t, c_void_p]),
     "rln_set_dense_arith": (c_int, [c_void_p, c_int, c_int, c_int, c_int]),
     "rln_op_convt": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
                              c_int, c_int, c_void_p]),

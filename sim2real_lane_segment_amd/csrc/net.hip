@@ -23,6 +23,7 @@
 #include "dense3.h"
 #include "pw1.h"
 #include "ct3.h"
+#include "fc3.h"
 #include "igemm.h"
 #include "pointwise.h"
 
@@ -492,6 +493,10 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
       igemm_tile_dims(IG_CONV3_BN, tile, &th, &tw);
       const size_t blocks = (size_t)n * ((Hd + th - 1) / th) * ((Wd + tw - 1) / tw);
       stat_max = std::max(stat_max, blocks * o.cout * 2);
+      if (o.type == OP_FIRST) {
+        stat_max = std::max(stat_max, (size_t)512 * o.cout * 2);
+        wp_max = std::max(wp_max, (size_t)512 * o.cout * o.cin * 9);
+      }
       if (o.type == OP_DENSE && c->d3_fwd_np > 0) {
         int dth, dtw, drg;
         d3_fwd_pick_tile(Hd, Wd, c->d3_fwd_np, &dth, &dtw, &drg);
@@ -971,6 +976,33 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
       return 0;
     }
   }
+  if (o.type == OP_FIRST && c->d3_fwd_np > 0) {  // split-operand 16-bit MFMA kernel (fc3.h)
+    F3Fwd q;
+    memset(&q, 0, sizeof(q));
+    q.X = x;
+    q.Cin = o.cin;
+    q.H = dl.H;
+    q.W = dl.W;
+    q.N = N;
+    q.w = p.w;
+    q.bias = p.bias;
+    q.out = p.out;
+    q.out_ns = p.out_ns;
+    q.out_cs = p.out_cs;
+    q.Cout = o.cout;
+    q.stat_partial = p.stat_partial;
+    if (f3_fwd_supported(q)) {
+      f3_fwd_plan(&q);
+      {
+        const double flops = 2.0 * o.cin * o.cout * 9.0 * dl.H * dl.W * N;
+        const double bytes = 4.0 * N * ((double)o.cin + o.cout) * dl.H * dl.W;
+        ProfScope ps(c, PC_FIRST_FWD, flops, bytes, s);
+        RLN_TRY(f3_fwd_launch(q, c->d3_fwd_np, c->d3_fwd_dt, s));
+      }
+      if (training) RLN_TRY(finalize_stats(c, o.dst_level, o.out_off, o.cout, (long long)q.blocks, s, (long long)k));
+      return 0;
+    }
+  }
   if (o.type == OP_TU && c->d3_fwd_np > 0 && c->c3_wf_off[k] >= 0) {  // split-operand 16-bit MFMA kernel (ct3.h)
     const Level& sl = c->levels[o.src_level];
     C3Fwd q;
@@ -1319,9 +1351,36 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
         RLN_TRY(run_wgrad(c, WG_DENSE3, w, o.cout, o.cin, o.conv.w, ws));
       }
     } else {
-      w.v = c->last_x;
-      w.v_ns = (long long)o.cin * plane;
-      RLN_TRY(run_wgrad(c, WG_RAW3, w, o.cout, o.cin, o.conv.w, ws));
+      bool done = false;
+      if (c->d3_bwd_np > 0) {  // split-operand 16-bit MFMA kernel (fc3.h)
+        F3Wgrad g;
+        memset(&g, 0, sizeof(g));
+        g.X = c->last_x;
+        g.Cin = o.cin;
+        g.H = lv.H;
+        g.W = lv.W;
+        g.N = N;
+        g.dY = c->dY;
+        g.Cout = o.cout;
+        g.partial = c->wpartial;
+        if (f3_wgrad_supported(g)) {
+          f3_wgrad_plan(&g);
+          {
+            const double flops = 2.0 * o.cin * o.cout * 9.0 * plane * N;
+            const double bytes = 4.0 * N * ((double)o.cin + o.cout) * plane;
+            ProfScope ps(c, PC_FIRST_WGRAD, flops, bytes, ws);
+            RLN_TRY(f3_wgrad_launch(g, c->d3_bwd_np, c->d3_bwd_dt, ws));
+          }
+          ProfScope ps2(c, PC_REDUCE, 0, 4.0 * (g.blocks + 1) * w.wsize, ws);
+          RLN_TRY(reduce_rows(c->wpartial, g.blocks, w.wsize, c->grads + o.conv.w, ws));
+          done = true;
+        }
+      }
+      if (!done) {
+        w.v = c->last_x;
+        w.v_ns = (long long)o.cin * plane;
+        RLN_TRY(run_wgrad(c, WG_RAW3, w, o.cout, o.cin, o.conv.w, ws));
+      }
     }
     RLN_TRY(wg_end(c));
   } else if (o.type == OP_TD) {
@@ -2476,6 +2535,59 @@ int rln_op_td_bwd(const float* x, const float* dyp, const uint8_t* pool_idx, con
     RLN_TRY(p1_wgrad_launch(gw, parts, dtype, s));
     RLN_TRY(reduce_rows(wpart, gw.nranges, (long long)cin * cout, dw, s));
   }
+  return 0;
+}
+
+int rln_op_fc_fwd(const float* x, int n, int cin, int h, int w, const float* weight, const float* bias, int cout,
+                  float* out, int out_ctot, int out_coff, float* stats, int parts, int dtype, void* workspace,
+                  size_t workspace_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!x || !weight || !out || !workspace) return fail(RLN_ERR_ARG, "null pointer");
+  const size_t plane = (size_t)h * w;
+  F3Fwd p;
+  memset(&p, 0, sizeof(p));
+  p.X = x;
+  p.Cin = cin;
+  p.H = h;
+  p.W = w;
+  p.N = n;
+  p.w = weight;
+  p.bias = bias;
+  p.out = out + (size_t)out_coff * plane;
+  p.out_ns = (long long)out_ctot * plane;
+  p.out_cs = (int)plane;
+  p.Cout = cout;
+  if (!f3_fwd_supported(p)) return fail(RLN_ERR_UNSUPPORTED, "geometry not covered by the first-conv forward kernel");
+  f3_fwd_plan(&p);
+  Carver cv(workspace);
+  float* partial = stats ? cv.take<float>((size_t)p.blocks * cout * 2) : nullptr;
+  if (cv.off > workspace_bytes) return fail(RLN_ERR_WORKSPACE, "workspace of %zu bytes needed", cv.off);
+  p.stat_partial = partial;
+  RLN_TRY(f3_fwd_launch(p, parts, dtype, s));
+  if (stats) RLN_TRY(reduce_rows(partial, p.blocks, (long long)cout * 2, stats, s));
+  return 0;
+}
+
+int rln_op_fc_wgrad(const float* x, const float* dy, int n, int cin, int cout, int h, int w, float* dw, int parts, int dtype,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!x || !dy || !dw || !workspace) return fail(RLN_ERR_ARG, "null pointer");
+  F3Wgrad g;
+  memset(&g, 0, sizeof(g));
+  g.X = x;
+  g.Cin = cin;
+  g.H = h;
+  g.W = w;
+  g.N = n;
+  g.dY = dy;
+  g.Cout = cout;
+  if (!f3_wgrad_supported(g)) return fail(RLN_ERR_UNSUPPORTED, "geometry not covered by the first-conv weight-gradient kernel");
+  f3_wgrad_plan(&g);
+  Carver cv(workspace);
+  g.partial = cv.take<float>((size_t)g.blocks * cout * cin * 9);
+  if (cv.off > workspace_bytes) return fail(RLN_ERR_WORKSPACE, "workspace of %zu bytes needed", cv.off);
+  RLN_TRY(f3_wgrad_launch(g, parts, dtype, s));
+  RLN_TRY(reduce_rows(g.partial, g.blocks, (long long)cout * cin * 9, dw, s));
   return 0;
 }
 
