@@ -1,0 +1,26 @@
+"""Eval-forward latency / throughput at the reference's demo size: N = 1 and N = 16 at 480x640,
+FCDenseNet67, default arithmetic and the plain-bf16-operand mode.  Prints one line per case."""
+import sys
+import torch
+sys.path.insert(0, ".")
+from oracle import fcdensenet_oracle as O  # deterministic initialiser only
+from sim2real_lane_segment_amd.engine import Engine, NetSpec, parse_dense_arith
+
+st = O.init_state(O.NetConfig(), 3)
+for mode in ("f16x2,bf16x2", "bf16x1,bf16x1"):
+    for n in (1, 16):
+        eng = Engine(NetSpec(n_classes=4), device="cuda", dense_arith=parse_dense_arith(mode))
+        eng.load_state(st)
+        x = torch.randn(n, 3, 480, 640, device="cuda")
+        for _ in range(3):
+            eng.forward(x, training=False)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 10
+        e0.record()
+        for _ in range(reps):
+            eng.forward(x, training=False)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        print(f"{mode:14s} N={n:2d} 480x640: {ms:7.2f} ms / forward, {n / ms * 1e3:7.1f} frames/s")
