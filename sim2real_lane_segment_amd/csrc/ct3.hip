@@ -11,9 +11,6 @@ namespace rln {
 constexpr int C3_LDS_BUDGET = 150 * 1024;
 constexpr int C3_MT = 2;  // M tiles per block at most (LDS: 9 taps x K steps x parts per tile)
 
-__device__ __forceinline__ void lds_addf(float* p, float v) {
-  (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
 // lane i <- lane i-1 within a 16-lane row (lane 0 <- 0)
 __device__ __forceinline__ unsigned row_from_prev(unsigned v) {
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
@@ -296,8 +293,8 @@ __global__ __launch_bounds__(512, 2) void c3_fwd_k(const C3Fwd p) {
             s2 = row16_sum(s2);
             if (n16 == 0) {
               float* sl = slot + ((wave * p.mt * 16) + ol) * 2;
-              lds_addf(sl, s1);
-              lds_addf(sl + 1, s2);
+              lds_add_f32(sl, s1);
+              lds_add_f32(sl + 1, s2);
             }
           }
         }

@@ -9,10 +9,6 @@ namespace rln {
 
 constexpr int F3_MT = 4;  // M tiles (16 output channels each) at most
 
-__device__ __forceinline__ void f3_lds_add(float* p, float v) {
-  (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
 // =============================================================================================
 // forward: out[o][p] = bias[o] + sum_{k = c*9 + tap < Cin*9} W[o][k] * x[c][p + tap]
 //
@@ -116,8 +112,8 @@ __global__ __launch_bounds__(256, 2) void f3_fwd_k(const F3Fwd p) {
           s1 = row16_sum(s1);
           s2 = row16_sum(s2);
           if (n16 == 0) {
-            f3_lds_add(slot + ((wave * F3_MT * 16) + m * 16 + kb4 + r) * 2, s1);
-            f3_lds_add(slot + ((wave * F3_MT * 16) + m * 16 + kb4 + r) * 2 + 1, s2);
+            lds_add_f32(slot + ((wave * F3_MT * 16) + m * 16 + kb4 + r) * 2, s1);
+            lds_add_f32(slot + ((wave * F3_MT * 16) + m * 16 + kb4 + r) * 2 + 1, s2);
           }
         }
       }

@@ -10,10 +10,6 @@ namespace rln {
 
 constexpr int P1_LDS_BUDGET = 150 * 1024;
 
-__device__ __forceinline__ void lds_add(float* p, float v) {
-  (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
 // =============================================================================================
 // weight packing
 // =============================================================================================
@@ -281,8 +277,8 @@ __global__ __launch_bounds__(512, 2) void p1_fwd_k(const P1Fwd p) {
           const float s2 = row16_sum(st ? best * best : 0.f);
           if (n16 == 0) {  // LDS float adds without return: nothing to wait for; one wave per slot, issue order = sum order
             float* sl = slot + ((wave * p.mt * 16) + ol) * 2;
-            lds_add(sl, s1);
-            lds_add(sl + 1, s2);
+            lds_add_f32(sl, s1);
+            lds_add_f32(sl + 1, s2);
           }
         }
       }
@@ -537,8 +533,8 @@ __global__ __launch_bounds__(512, 2) void p1_dgrad_k(const P1Dgrad p) {
           a2 = row16_sum(a2);
           if (n16 == 0) {
             float* sl = slot + ((wave * p.mt * 16) + cl) * 2;
-            lds_add(sl, a1);
-            lds_add(sl + 1, a2);
+            lds_add_f32(sl, a1);
+            lds_add_f32(sl + 1, a2);
           }
         }
       }

@@ -85,4 +85,10 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+// LDS float add without return value (ds_add_f32): nothing to wait for.  Used for per-wave statistics slots that one wave
+// owns, so the issue order is the summation order (deterministic).
+__device__ __forceinline__ void lds_add_f32(float* p, float v) {
+  (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 }  // namespace rln
