@@ -91,6 +91,10 @@ int64_t rln_dropout_channels(const rln_ctx* ctx, int* per_call /* may be NULL, e
  *                  (csrc/dense3.h; 2 parts = 3 products ~ 2^-17 (bf16) / 2^-22 (f16), 3 bf16 parts = 6 products < fp32 eps).
  * fwd_* selects the forward kernels, bwd_* the data / weight gradient kernels.  Call before rln_workspace_bytes. */
 int rln_set_dense_arith(rln_ctx* ctx, int fwd_parts, int fwd_dtype, int bwd_parts, int bwd_dtype);
+/* Parts of the ACTIVATION operand in the dense weight-gradient GEMMs (sums over N*H*W pixels, where the rounding of the
+ * activations to one 16-bit part averages out: measured gradient error next to the other modes in tools/grad_err_probe.py).
+ * rln_set_dense_arith resets it to 1 for two-part backward arithmetic and to bwd_parts otherwise; 0 = bwd_parts. */
+int rln_set_wgrad_activation_parts(rln_ctx* ctx, int parts);
 
 int rln_bind_params(rln_ctx* ctx, float* params, float* grads, float* bn_running, int64_t* num_batches_tracked);
 

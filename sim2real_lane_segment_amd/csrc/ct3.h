@@ -56,6 +56,7 @@ struct C3Fwd {
   int mt, groups, bpg;
 };
 bool c3_fwd_supported(const C3Fwd& p);
+bool c3_fwd_fits(const C3Fwd& p, int np);  // one M tile (9 taps x K steps x parts) fits the LDS budget
 void c3_fwd_plan(C3Fwd* p, int np);
 int c3_fwd_launch(const C3Fwd& p, int np, int dt, hipStream_t s);
 

@@ -327,6 +327,11 @@ bool c3_fwd_supported(const C3Fwd& p) {
   return true;
 }
 
+bool c3_fwd_fits(const C3Fwd& p, int np) {
+  const int KS = (p.Cin + 31) / 32;
+  return (size_t)KS * 9 * np * 1024 + 16 * 4 + 8 * 32 * 4 <= (size_t)C3_LDS_BUDGET;
+}
+
 void c3_fwd_plan(C3Fwd* p, int np) {
   const int KS = (p->Cin + 31) / 32;
   c3_group_plan((p->Cout + 15) / 16, KS, np, &p->mt, &p->groups);

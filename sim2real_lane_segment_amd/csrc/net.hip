@@ -167,6 +167,7 @@ struct rln_ctx {
   const float* gext = nullptr;  // loss_mode 2: caller-supplied gradient of the probabilities
   // dense-layer arithmetic (rln_set_dense_arith): 0 parts = exact fp32 MFMA kernels, else split 16-bit MFMA (dense3.h)
   int d3_fwd_np = 0, d3_fwd_dt = 0, d3_bwd_np = 0, d3_bwd_dt = 0;
+  int wg_act_parts = 1;  // parts of the ACTIVATION operand in the dense weight gradients (1: leading part only)
   std::vector<D3PackDesc> d3_desc_f, d3_desc_b;  // host copies, one entry per dense op
   std::vector<long long> d3_wf_off, d3_wb_off;   // per op index (uint4 units into d3_packed), -1: none
   D3PackDesc* d3_desc_f_dev = nullptr;
@@ -1023,7 +1024,7 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
     q.Ho = dl.H;
     q.Wo = dl.W;
     q.stat_partial = p.stat_partial;
-    if (c3_fwd_supported(q)) {
+    if (c3_fwd_supported(q) && c3_fwd_fits(q, c->d3_fwd_np)) {
       c3_fwd_plan(&q, c->d3_fwd_np);
       {
         const double flops = 2.0 * o.cin * o.cout * 9.0 * sl.H * sl.W * N;
@@ -1776,6 +1777,7 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
       g.partial = c->wpartial;
       if (d3_wgrad_supported(g)) {  // transposed-read 16-bit MFMA kernel
         d3_wgrad_plan(lv.H, lv.W, N, o.cin, &g);
+        g.nz = c->wg_act_parts;
 #ifdef RLN_DIAG
         if (rln_env("RLN_D3_DBG")) g.dbg = atoi(rln_env("RLN_D3_DBG"));
 #endif
@@ -1966,8 +1968,15 @@ int rln_set_dense_arith(rln_ctx* c, int fwd_parts, int fwd_dtype, int bwd_parts,
   c->d3_fwd_dt = fwd_dtype;
   c->d3_bwd_np = bwd_parts;
   c->d3_bwd_dt = bwd_dtype;
+  c->wg_act_parts = bwd_parts == 2 ? 1 : bwd_parts;  // see rln_set_wgrad_activation_parts
   c->levels[0].S = nullptr;  // the workspace layout depends on the mode: it has to be set again
   c->N = c->H = c->W = 0;
+  return 0;
+}
+
+int rln_set_wgrad_activation_parts(rln_ctx* c, int parts) {
+  if (parts < 0 || parts > 3) return fail(RLN_ERR_ARG, "parts in 0..3 (0 = as many as the backward arithmetic)");
+  c->wg_act_parts = (parts == 0 || parts > c->d3_bwd_np) ? c->d3_bwd_np : parts;
   return 0;
 }
 

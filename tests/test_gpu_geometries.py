@@ -35,3 +35,68 @@ def test_split_arithmetic_matches_exact_family(n, h, w):
     assert int((pa.argmax(1) != pb.argmax(1)).sum()) <= 2          # near-ties only; 0 at these seeds
     assert abs(la - lb) < 1e-5 * max(1.0, abs(la))
     assert float((ga - gb).norm() / ga.norm()) < 2e-3              # bf16x2 backward: measured 1e-4 .. 6e-4
+
+
+def test_wgrad_activation_parts_setting():
+    """The dense weight gradients take the activations' leading bf16 part only by default (two-part backward mode);
+    rln_set_wgrad_activation_parts(0) restores both parts.  Both stay at the noise level of the exact family."""
+    from oracle import fcdensenet_oracle as O
+    from sim2real_lane_segment_amd.engine import Engine, NetSpec, parse_dense_arith
+    cfg = O.NetConfig()
+    st = O.init_state(cfg, 3)
+    g = torch.Generator().manual_seed(77)
+    n, h, w = 2, 120, 160
+    x = torch.randn(n, 3, h, w, generator=g).cuda()
+    y = torch.randint(0, 4, (n, h, w), generator=g).cuda()
+    scales = O.make_drop_scales(cfg, n, 11)
+    grads = {}
+    for name, mode, parts in (("exact", "fp32,fp32", None), ("default", "f16x2,bf16x2", None), ("full", "f16x2,bf16x2", 0)):
+        eng = Engine(NetSpec(n_classes=4), device="cuda", dense_arith=parse_dense_arith(mode))
+        if parts is not None:
+            eng.set_wgrad_activation_parts(parts)
+        eng.load_state(st)
+        probs_t, _ = eng.forward(x, training=True, with_backward=True, drop_scales=eng.pack_drop_scales(scales))
+        eng.loss(probs_t, y, weighted=True)
+        eng.backward(1.0)
+        torch.cuda.synchronize()
+        grads[name] = eng.grads.clone().cpu()
+    ref = grads["exact"]
+    e_def = float((grads["default"] - ref).norm() / ref.norm())
+    e_full = float((grads["full"] - ref).norm() / ref.norm())
+    print(f"[wgrad activation parts] rel-L2 vs exact family: leading part only {e_def:.2e}, both parts {e_full:.2e}")
+    assert e_full < 2e-3 and e_def < 2e-3
+    assert float((grads["default"] - grads["full"]).abs().max()) > 0.0  # the setting reaches the kernels
+
+
+@pytest.mark.parametrize("variant", ["57", "103"])
+@pytest.mark.parametrize("mode", ["bf16x3,bf16x3", "bf16x1,bf16x1", "f16x2,bf16x2"])
+def test_variants_in_every_arithmetic_mode(variant, mode):
+    """FCDenseNet57 (growth 12) / 103 (TransitionUp with up to 192 channels: the 3-part fragments of one M tile exceed LDS
+    and the launch must hand over to the exact-fp32 kernel) run one training step in every arithmetic mode."""
+    from oracle import fcdensenet_oracle as O
+    from sim2real_lane_segment_amd.engine import Engine, NetSpec, parse_dense_arith
+    from sim2real_lane_segment_amd.models.FCDenseNet import tiramisu as T
+    down, up, bott, growth = T._VARIANTS[variant]
+    cfg = O.NetConfig(down_blocks=down, up_blocks=up, bottleneck_layers=bott, growth_rate=growth, n_classes=4)
+    spec = NetSpec(in_channels=3, down_blocks=down, up_blocks=up, bottleneck_layers=bott, growth_rate=growth,
+                   out_chans_first_conv=cfg.out_chans_first_conv, n_classes=4)
+    st = O.init_state(cfg, 21)
+    g = torch.Generator().manual_seed(22)
+    n, h, w = 2, 64, 96
+    x = torch.randn(n, 3, h, w, generator=g).cuda()
+    y = torch.randint(0, 4, (n, h, w), generator=g).cuda()
+    scales = O.make_drop_scales(cfg, n, 23)
+    res = {}
+    for m in ("fp32,fp32", mode):
+        eng = Engine(spec, device="cuda", dense_arith=parse_dense_arith(m))
+        eng.load_state(st)
+        probs_t, _ = eng.forward(x, training=True, with_backward=True, drop_scales=eng.pack_drop_scales(scales))
+        out, _, _ = eng.loss(probs_t, y, weighted=True)
+        eng.backward(1.0)
+        torch.cuda.synchronize()
+        res[m] = (probs_t.float().cpu(), float(out[0]), eng.grads.clone().cpu())
+    (pa, la, ga), (pb, lb, gb) = res["fp32,fp32"], res[mode]
+    one_part = mode.startswith("bf16x1")
+    assert float((pa - pb).abs().max()) < (5e-2 if one_part else 1e-4)
+    assert abs(la - lb) < (2e-2 if one_part else 1e-5) * max(1.0, abs(la))
+    assert float((ga - gb).norm() / ga.norm()) < (0.5 if one_part else 5e-3)
