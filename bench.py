@@ -364,7 +364,7 @@ def main():
             parts = fwd_parts if dom["name"] == "dense3_fwd" else bwd_parts
             products = {1: 1, 2: 3, 3: 6}.get(parts, 1) if dom["name"] in SPLIT_CLASSES else 1
             if dom["name"] == "dense3_wgrad" and parts == 2:
-                products = 2  # the activation operand contributes its leading part only (rln_set_wgrad_activation_parts)
+                products = 1  # one-part operands in the dense weight gradient (rln_set_wgrad_parts)
             mfma_peak = PEAK_16BIT_MFMA_TFLOPS if dom["name"] in SPLIT_CLASSES else PEAK_F32_MFMA_TFLOPS
             tfl = dom["flops"] / (dom["ms"] * 1e-3) / 1e12          # algorithmic flops (2 per multiply-add)
             gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9           # algorithmic bytes

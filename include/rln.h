@@ -91,10 +91,12 @@ int64_t rln_dropout_channels(const rln_ctx* ctx, int* per_call /* may be NULL, e
  *                  (csrc/dense3.h; 2 parts = 3 products ~ 2^-17 (bf16) / 2^-22 (f16), 3 bf16 parts = 6 products < fp32 eps).
  * fwd_* selects the forward kernels, bwd_* the data / weight gradient kernels.  Call before rln_workspace_bytes. */
 int rln_set_dense_arith(rln_ctx* ctx, int fwd_parts, int fwd_dtype, int bwd_parts, int bwd_dtype);
-/* Parts of the ACTIVATION operand in the dense weight-gradient GEMMs (sums over N*H*W pixels, where the rounding of the
- * activations to one 16-bit part averages out: measured gradient error next to the other modes in tools/grad_err_probe.py).
- * rln_set_dense_arith resets it to 1 for two-part backward arithmetic and to bwd_parts otherwise; 0 = bwd_parts. */
-int rln_set_wgrad_activation_parts(rln_ctx* ctx, int parts);
+/* Operand parts of the dense 3x3 weight-gradient GEMMs (d3_wgrad_k).  Every entry of dW is a sum over N*H*W pixels
+ * (>= 2400 where this kernel runs), over which the 16-bit rounding of the operands averages out: with ONE bf16 part
+ * (plain bf16 MFMA, fp32 accumulation) the gradient error against the exact-fp32 family is 5.8e-4 (relative L2 over all
+ * parameters, FCDenseNet67 2x120x160) against 4.3e-4 with two parts (tests/test_gpu_geometries.py).  rln_set_dense_arith
+ * resets it to 1 for two-part backward arithmetic and to bwd_parts otherwise; 0 = bwd_parts. */
+int rln_set_wgrad_parts(rln_ctx* ctx, int parts);
 
 int rln_bind_params(rln_ctx* ctx, float* params, float* grads, float* bn_running, int64_t* num_batches_tracked);
 

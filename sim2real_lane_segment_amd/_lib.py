@@ -78,7 +78,7 @@ _PROTOS = {
     "rln_op_fc_wgrad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p,
                                 c_size_t, c_void_p]),
     "rln_set_dense_arith": (c_int, [c_void_p, c_int, c_int, c_int, c_int]),
-    "rln_set_wgrad_activation_parts": (c_int, [c_void_p, c_int]),
+    "rln_set_wgrad_parts": (c_int, [c_void_p, c_int]),
     "rln_op_convt": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
                              c_int, c_int, c_void_p]),
     "rln_profile_enable": (c_int, [c_void_p, c_int]),

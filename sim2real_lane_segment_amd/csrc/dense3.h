@@ -81,7 +81,6 @@ struct D3Wgrad {
   int rg;
   int nchunks, nranges;
   float* partial;  // [nranges][Cout*Cin*9], layout [o][c][tap]
-  int nz;          // parts of the activation operand (1 = leading part only; 0 / np = all parts)
   int dbg;         // diagnostic builds (-DRLN_DIAG) only: 1 no global loads, 2 no commit, 4 no MFMA phase
 };
 bool d3_wgrad_supported(const D3Wgrad& p);

@@ -499,8 +499,7 @@ __device__ __forceinline__ uint2 lds_tr16(const unsigned char* p) {
   return c.u;
 }
 
-// NZ = parts of the activation operand z (<= NP): with NZ < NP the products are a_i * z_0.. only (see d3_wgrad_products)
-template <int NP, int DT, int NZ>
+template <int NP, int DT>
 __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -510,8 +509,8 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
   const int PLZ = rows * P * 32;          // one part of the z image
   const int npix = p.th * p.tw;           // 320
   const int PLY = npix * 32;              // one part of the dY image
-  const int ZB = NZ * PLZ, YB = NP * PLY; // one buffer each
-  unsigned char* zbuf = smem;             // [2][NZ][PLZ]
+  const int ZB = NP * PLZ, YB = NP * PLY; // one buffer each
+  unsigned char* zbuf = smem;             // [2][NP][PLZ]
   unsigned char* ybuf = smem + 2 * ZB;    // [2][NP][PLY]
   float* abtab = reinterpret_cast<float*>(smem + 2 * ZB + 2 * YB);  // a[16], b[16] of this chunk
 
@@ -628,11 +627,11 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
           const float x = h_side ? reg[k].x : reg[k].w;
           zv[k] = okf ? fmaxf(fmaf(abtab[4 * u_o + k], x, abtab[16 + 4 * u_o + k]), 0.f) : 0.f;
         }
-        unsigned pa[NZ], pb2[NZ];
-        split2<DT, NZ>(zv[0], zv[1], pa);
-        split2<DT, NZ>(zv[2], zv[3], pb2);
+        unsigned pa[NP], pb2[NP];
+        split2<DT, NP>(zv[0], zv[1], pa);
+        split2<DT, NP>(zv[2], zv[3], pb2);
 #pragma unroll
-        for (int pt = 0; pt < NZ; ++pt) *reinterpret_cast<uint2*>(zb + pt * PLZ + u_lds) = make_uint2(pa[pt], pb2[pt]);
+        for (int pt = 0; pt < NP; ++pt) *reinterpret_cast<uint2*>(zb + pt * PLZ + u_lds) = make_uint2(pa[pt], pb2[pt]);
         return;
       }
       // kind 0: z = relu(a*x + b) of 8 channels x 4 pixels; kind 1: dY as it is (zero beyond Cout); zero outside
@@ -646,7 +645,7 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
       const int plane = kind == 0 ? PLZ : PLY;
 #pragma unroll
       for (int px = 0; px < 4; ++px) {
-        float zz[8];
+        unsigned parts[4][NP];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const float4 u0 = reg[2 * k], u1 = reg[2 * k + 1];
@@ -657,26 +656,12 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
             z0 = fmaxf(z0, 0.f);
             z1 = fmaxf(z1, 0.f);
           }
-          zz[2 * k] = okf ? z0 : 0.f;
-          zz[2 * k + 1] = okf ? z1 : 0.f;
+          split2<DT, NP>(okf ? z0 : 0.f, okf ? z1 : 0.f, parts[k]);
         }
-        if (kind == 0) {  // z: NZ parts
-          unsigned parts[4][NZ];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) split2<DT, NZ>(zz[2 * k], zz[2 * k + 1], parts[k]);
-#pragma unroll
-          for (int pt = 0; pt < NZ; ++pt)
-            *reinterpret_cast<uint4*>(dst + pt * plane + px * 32) =
-                make_uint4(parts[0][pt], parts[1][pt], parts[2][pt], parts[3][pt]);
-        } else {  // dY: NP parts
-          unsigned parts[4][NP];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) split2<DT, NP>(zz[2 * k], zz[2 * k + 1], parts[k]);
-#pragma unroll
-          for (int pt = 0; pt < NP; ++pt)
-            *reinterpret_cast<uint4*>(dst + pt * plane + px * 32) =
-                make_uint4(parts[0][pt], parts[1][pt], parts[2][pt], parts[3][pt]);
-        }
+        for (int pt = 0; pt < NP; ++pt)
+          *reinterpret_cast<uint4*>(dst + pt * plane + px * 32) =
+              make_uint4(parts[0][pt], parts[1][pt], parts[2][pt], parts[3][pt]);
       }
     };
     // tile t0+i lives in set i & 1.  Iteration i (consumers multiply tile i): commit tile i+1, refill its set with i+3.
@@ -736,7 +721,7 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
       // a K-step a wave does not own runs with a zero dY fragment (adds nothing) so that all four waves share one code path
       constexpr int DEPTH = 3, RING = DEPTH + 1;
       const int STEPS = nks * 9;  // wave-uniform: 27 (waves 0, 1) or 18 (waves 2, 3)
-      uint4 af[2][NP], bfr[RING][NZ];
+      uint4 af[2][NP], bfr[RING][NP];
       auto load_a = [&](int k, uint4 (&dst)[NP]) __attribute__((always_inline)) {
 #pragma unroll
         for (int pt = 0; pt < NP; ++pt) {
@@ -744,11 +729,11 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
           dst[pt] = make_uint4(lo.x, lo.y, hi.x, hi.y);
         }
       };
-      auto load_b = [&](int st, uint4 (&dst)[NZ]) __attribute__((always_inline)) {
+      auto load_b = [&](int st, uint4 (&dst)[NP]) __attribute__((always_inline)) {
         const int k = st / 9, t = st - k * 9;
         const int toff = ((t / 3 - 1) * P + (t % 3 - 1)) * 32;
 #pragma unroll
-        for (int pt = 0; pt < NZ; ++pt) {
+        for (int pt = 0; pt < NP; ++pt) {
           const uint2 lo = lds_tr16(zb + pt * PLZ + za[k][0] + toff), hi = lds_tr16(zb + pt * PLZ + za[k][1] + toff);
           dst[pt] = make_uint4(lo.x, lo.y, hi.x, hi.y);
         }
@@ -766,7 +751,7 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
         if (st < STEPS) {  // wave-uniform
           if (st + DEPTH < KS * 9) load_b(st + DEPTH, bfr[(st + DEPTH) % RING]);  // past the wave's steps: clamped, unused
           if (t == 9 - DEPTH && k + 1 < KS) load_a(k + 1, af[(k + 1) & 1]);
-          acc[t] = mfma_mixed<DT, NP, NZ>(af[k & 1], bfr[st % RING], acc[t]);
+          acc[t] = mfma_split<DT, NP>(af[k & 1], bfr[st % RING], acc[t]);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -827,12 +812,12 @@ void d3_wgrad_plan(int H, int W, int N, int Cin, D3Wgrad* p) {
   p->nranges = (int)((total + per - 1) / per);  // no empty ranges
 }
 
-template <int NP, int DT, int NZ>
-static int d3_wgrad_launch_z(const D3Wgrad& p, hipStream_t s) {
+template <int NP, int DT>
+static int d3_wgrad_launch_t(const D3Wgrad& p, hipStream_t s) {
   const int P = p.tw + 3, rows = p.th + 2;
-  const size_t lds = (size_t)2 * NZ * rows * P * 32 + (size_t)2 * NP * p.th * p.tw * 32 + 128;
+  const size_t lds = (size_t)2 * NP * rows * P * 32 + (size_t)2 * NP * p.th * p.tw * 32 + 128;
   if (lds > 160 * 1024 || lds < 4 * 9 * 64 * 16) return -4;
-  auto kern = d3_wgrad_k<NP, DT, NZ>;
+  auto kern = d3_wgrad_k<NP, DT>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -842,12 +827,6 @@ static int d3_wgrad_launch_z(const D3Wgrad& p, hipStream_t s) {
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(p.nchunks * p.nranges)), dim3(768), lds, s, p);
   return (int)hipGetLastError();
-}
-
-template <int NP, int DT>
-static int d3_wgrad_launch_t(const D3Wgrad& p, hipStream_t s) {
-  if (p.nz == 1 && NP > 1) return d3_wgrad_launch_z<NP, DT, 1>(p, s);
-  return d3_wgrad_launch_z<NP, DT, NP>(p, s);
 }
 
 int d3_wgrad_launch(const D3Wgrad& p, int np, int dt, hipStream_t s) {

@@ -167,7 +167,7 @@ struct rln_ctx {
   const float* gext = nullptr;  // loss_mode 2: caller-supplied gradient of the probabilities
   // dense-layer arithmetic (rln_set_dense_arith): 0 parts = exact fp32 MFMA kernels, else split 16-bit MFMA (dense3.h)
   int d3_fwd_np = 0, d3_fwd_dt = 0, d3_bwd_np = 0, d3_bwd_dt = 0;
-  int wg_act_parts = 1;  // parts of the ACTIVATION operand in the dense weight gradients (1: leading part only)
+  int wg_parts = 0;  // operand parts of the dense 3x3 weight-gradient GEMMs (rln_set_wgrad_parts)
   std::vector<D3PackDesc> d3_desc_f, d3_desc_b;  // host copies, one entry per dense op
   std::vector<long long> d3_wf_off, d3_wb_off;   // per op index (uint4 units into d3_packed), -1: none
   D3PackDesc* d3_desc_f_dev = nullptr;
@@ -1777,7 +1777,6 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
       g.partial = c->wpartial;
       if (d3_wgrad_supported(g)) {  // transposed-read 16-bit MFMA kernel
         d3_wgrad_plan(lv.H, lv.W, N, o.cin, &g);
-        g.nz = c->wg_act_parts;
 #ifdef RLN_DIAG
         if (rln_env("RLN_D3_DBG")) g.dbg = atoi(rln_env("RLN_D3_DBG"));
 #endif
@@ -1785,7 +1784,7 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
           const double wflops = 2.0 * o.cout * o.cin * 9.0 * plane * N;
           const double wbytes = 4.0 * N * ((double)o.cout + o.cin) * plane;
           ProfScope ps(c, PC_D3_WGRAD, wflops, wbytes, s);
-          RLN_TRY(d3_wgrad_launch(g, c->d3_bwd_np, c->d3_bwd_dt, s));
+          RLN_TRY(d3_wgrad_launch(g, c->wg_parts, c->d3_bwd_dt, s));
         }
         ProfScope ps2(c, PC_REDUCE, 0, 4.0 * (g.nranges + 1) * w.wsize, s);
         RLN_TRY(reduce_rows(c->wpartial, g.nranges, w.wsize, c->grads + o.conv.w, s));
@@ -1968,15 +1967,15 @@ int rln_set_dense_arith(rln_ctx* c, int fwd_parts, int fwd_dtype, int bwd_parts,
   c->d3_fwd_dt = fwd_dtype;
   c->d3_bwd_np = bwd_parts;
   c->d3_bwd_dt = bwd_dtype;
-  c->wg_act_parts = bwd_parts == 2 ? 1 : bwd_parts;  // see rln_set_wgrad_activation_parts
+  c->wg_parts = bwd_parts == 2 ? 1 : bwd_parts;  // see rln_set_wgrad_parts
   c->levels[0].S = nullptr;  // the workspace layout depends on the mode: it has to be set again
   c->N = c->H = c->W = 0;
   return 0;
 }
 
-int rln_set_wgrad_activation_parts(rln_ctx* c, int parts) {
+int rln_set_wgrad_parts(rln_ctx* c, int parts) {
   if (parts < 0 || parts > 3) return fail(RLN_ERR_ARG, "parts in 0..3 (0 = as many as the backward arithmetic)");
-  c->wg_act_parts = (parts == 0 || parts > c->d3_bwd_np) ? c->d3_bwd_np : parts;
+  c->wg_parts = (parts == 0 || parts > c->d3_bwd_np) ? c->d3_bwd_np : parts;
   return 0;
 }
 

@@ -76,21 +76,6 @@ __device__ __forceinline__ f32x4 mfma_split(const uint4 (&a)[NP], const uint4 (&
 }
 
 
-// the same with only NZ <= NP parts of the b operand: every cross term a_i * b_j with i + j < NP and j < NZ
-template <int DT, int NP, int NZ>
-__device__ __forceinline__ f32x4 mfma_mixed(const uint4 (&a)[NP], const uint4 (&b)[NZ], f32x4 c) {
-  if constexpr (NZ == NP) {
-    return mfma_split<DT, NP>(a, b, c);
-  } else {
-#pragma unroll
-    for (int i = NP - 1; i >= 0; --i)
-#pragma unroll
-      for (int j = NZ - 1; j >= 0; --j)
-        if (i + j < NP) c = mfma32<DT>(a[i], b[j], c);
-    return c;
-  }
-}
-
 // sum over the 16 lanes of a DPP row (lanes with equal l>>4): four rotate-adds, every lane receives the total
 __device__ __forceinline__ float row16_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, true));

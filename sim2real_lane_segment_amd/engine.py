@@ -181,9 +181,9 @@ class Engine:
         self._ws = None
         self._ws_key = None
 
-    def set_wgrad_activation_parts(self, parts):
-        """Parts of the activation operand in the dense weight gradients (rln_set_wgrad_activation_parts; 0 = all)."""
-        _lib.check(self.L.rln_set_wgrad_activation_parts(self.ctx, int(parts)), "rln_set_wgrad_activation_parts")
+    def set_wgrad_parts(self, parts):
+        """Operand parts of the dense weight-gradient GEMMs (rln_set_wgrad_parts; 0 = as the backward arithmetic)."""
+        _lib.check(self.L.rln_set_wgrad_parts(self.ctx, int(parts)), "rln_set_wgrad_parts")
 
     # ---- workspace ------------------------------------------------------------------------
     def _require_gpu(self):

@@ -37,9 +37,9 @@ def test_split_arithmetic_matches_exact_family(n, h, w):
     assert float((ga - gb).norm() / ga.norm()) < 2e-3              # bf16x2 backward: measured 1e-4 .. 6e-4
 
 
-def test_wgrad_activation_parts_setting():
-    """The dense weight gradients take the activations' leading bf16 part only by default (two-part backward mode);
-    rln_set_wgrad_activation_parts(0) restores both parts.  Both stay at the noise level of the exact family."""
+def test_wgrad_parts_setting():
+    """The dense weight-gradient GEMMs (sums over >= 2400 pixels) run on one bf16 operand part by default in the two-part
+    backward mode; rln_set_wgrad_parts(0) restores both parts.  Both stay at the noise level of the exact family."""
     from oracle import fcdensenet_oracle as O
     from sim2real_lane_segment_amd.engine import Engine, NetSpec, parse_dense_arith
     cfg = O.NetConfig()
@@ -53,7 +53,7 @@ def test_wgrad_activation_parts_setting():
     for name, mode, parts in (("exact", "fp32,fp32", None), ("default", "f16x2,bf16x2", None), ("full", "f16x2,bf16x2", 0)):
         eng = Engine(NetSpec(n_classes=4), device="cuda", dense_arith=parse_dense_arith(mode))
         if parts is not None:
-            eng.set_wgrad_activation_parts(parts)
+            eng.set_wgrad_parts(parts)
         eng.load_state(st)
         probs_t, _ = eng.forward(x, training=True, with_backward=True, drop_scales=eng.pack_drop_scales(scales))
         eng.loss(probs_t, y, weighted=True)
@@ -63,7 +63,7 @@ def test_wgrad_activation_parts_setting():
     ref = grads["exact"]
     e_def = float((grads["default"] - ref).norm() / ref.norm())
     e_full = float((grads["full"] - ref).norm() / ref.norm())
-    print(f"[wgrad activation parts] rel-L2 vs exact family: leading part only {e_def:.2e}, both parts {e_full:.2e}")
+    print(f"[wgrad parts] rel-L2 vs exact family: one part {e_def:.2e}, two parts {e_full:.2e}")
     assert e_full < 2e-3 and e_def < 2e-3
     assert float((grads["default"] - grads["full"]).abs().max()) > 0.0  # the setting reaches the kernels
 
