@@ -1232,6 +1232,12 @@ int wg_end(rln_ctx* c) {
   return 0;
 }
 
+// Operand parts of a weight-gradient GEMM whose K dimension runs over `pixels` positions: the reduced setting of
+// rln_set_wgrad_parts applies where the pixel sum is long enough for the operand rounding to average out.
+static inline int wgrad_parts(const rln_ctx* c, long long pixels) {
+  return (pixels >= 2400) ? c->wg_parts : c->d3_bwd_np;
+}
+
 int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
   const Op& o = c->ops[k];
   const int N = c->N;
@@ -1704,6 +1710,7 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
 // Returns kNotCovered when the block is not covered (caller falls back to the per-layer path), 0 on success.
 // ---------------------------------------------------------------------------------------------
 constexpr int kNotCovered = 1 << 20;
+
 int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
   const int L = k1 - k0 + 1;
   const Op& first = c->ops[(size_t)k0];
@@ -1784,7 +1791,7 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
           const double wflops = 2.0 * o.cout * o.cin * 9.0 * plane * N;
           const double wbytes = 4.0 * N * ((double)o.cout + o.cin) * plane;
           ProfScope ps(c, PC_D3_WGRAD, wflops, wbytes, s);
-          RLN_TRY(d3_wgrad_launch(g, c->wg_parts, c->d3_bwd_dt, s));
+          RLN_TRY(d3_wgrad_launch(g, wgrad_parts(c, (long long)N * lv.H * lv.W), c->d3_bwd_dt, s));
         }
         ProfScope ps2(c, PC_REDUCE, 0, 4.0 * (g.nranges + 1) * w.wsize, s);
         RLN_TRY(reduce_rows(c->wpartial, g.nranges, w.wsize, c->grads + o.conv.w, s));
