@@ -7,5 +7,5 @@ for d in "$@"; do
 import json,sys
 d=json.loads(sys.stdin.read())
 kc={k['name']:k['ms_per_step'] for k in d['kernel_classes']}
-print('dbg=$d', 'wgrad', kc.get('dense_conv3x3_wgrad'), 'fwd', kc.get('dense_conv3x3_fwd'), 'dgrad', kc.get('dense_conv3x3_dgrad'))"
+print('dbg=$d', 'd3_wgrad', kc.get('dense3_wgrad'), 'd3_fwd', kc.get('dense3_fwd'), 'd3_pull', kc.get('dense3_dgrad_pull'))"
 done
