@@ -585,10 +585,18 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
     const long long kns = kind == 1 ? (long long)p.Cout * p.cs : p.ns;
     float4 regA[8], regB[8];
     bool okA = false, okB = false;
-    auto issue = [&](int t, float4 (&reg)[8], bool& okf) __attribute__((always_inline)) {
-      const int n = t / tiles, tl = t - n * tiles;
-      const int tile_y = tl / p.tiles_x, tile_x = tl - tile_y * p.tiles_x;
-      const int gy0 = tile_y * p.th, gx0 = tile_x * p.tw;
+    // tiles are requested strictly in order t0, t0+1, ...: a cursor replaces two integer divisions per request
+    int cur_n = t0 / tiles, cur_ty = (t0 - cur_n * tiles) / p.tiles_x, cur_tx = (t0 - cur_n * tiles) - cur_ty * p.tiles_x;
+    auto issue = [&](int /*t: the cursor's tile*/, float4 (&reg)[8], bool& okf) __attribute__((always_inline)) {
+      const int n = cur_n;
+      const int gy0 = cur_ty * p.th, gx0 = cur_tx * p.tw;
+      if (++cur_tx == p.tiles_x) {
+        cur_tx = 0;
+        if (++cur_ty == p.tiles_y) {
+          cur_ty = 0;
+          ++cur_n;
+        }
+      }
       int iy, ix;
       bool ok;
       if (kind == 0) {
@@ -607,7 +615,7 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
       }
       const float* src = kbase + (long long)n * kns + (ok ? iy * p.W + ix : 0);
 #ifdef RLN_DIAG
-      if (!(p.dbg & 1))
+      if (!(p.dbg & 1) && !((p.dbg & 8) && kind == 1) && !((p.dbg & 16) && kind != 1))
 #endif
 #pragma unroll
       for (int cc = 0; cc < 8; ++cc) reg[cc] = *reinterpret_cast<const float4*>(src + choff[cc]);
@@ -664,30 +672,32 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
               make_uint4(parts[0][pt], parts[1][pt], parts[2][pt], parts[3][pt]);
       }
     };
-    // tile t0+i lives in set i & 1.  Iteration i (consumers multiply tile i): commit tile i+1, refill its set with i+3.
     __syncthreads();  // affine table
-    if (nt > 0) issue(t0, regA, okA);
-    if (nt > 1) issue(t0 + 1, regB, okB);
-    if (nt > 0) commit(0, regA, okA);
-    if (nt > 2) issue(t0 + 2, regA, okA);
-    __syncthreads();  // first tile staged
-    int i = 0;
-    for (; i + 4 < nt; i += 2) {  // steady state, two iterations per trip, no branches around the loads
-      commit(1, regB, okB);
-      issue(t0 + i + 3, regB, okB);
-      __syncthreads();
-      commit(0, regA, okA);
-      issue(t0 + i + 4, regA, okA);
-      __syncthreads();
-    }
-    for (; i < nt; ++i) {
-      if (i + 1 < nt) {
-        if ((i + 1) & 1) commit(1, regB, okB); else commit(0, regA, okA);
-        if (i + 3 < nt) {
-          if ((i + 3) & 1) issue(t0 + i + 3, regB, okB); else issue(t0 + i + 3, regA, okA);
-        }
+    {
+      // tile t0+i lives in set i & 1.  Iteration i (consumers multiply tile i): commit tile i+1, refill its set with i+3.
+      if (nt > 0) issue(t0, regA, okA);
+      if (nt > 1) issue(t0 + 1, regB, okB);
+      if (nt > 0) commit(0, regA, okA);
+      if (nt > 2) issue(t0 + 2, regA, okA);
+      __syncthreads();  // first tile staged
+      int i = 0;
+      for (; i + 4 < nt; i += 2) {  // steady state, two iterations per trip, no branches around the loads
+        commit(1, regB, okB);
+        issue(t0 + i + 3, regB, okB);
+        __syncthreads();
+        commit(0, regA, okA);
+        issue(t0 + i + 4, regA, okA);
+        __syncthreads();
       }
-      __syncthreads();
+      for (; i < nt; ++i) {
+        if (i + 1 < nt) {
+          if ((i + 1) & 1) commit(1, regB, okB); else commit(0, regA, okA);
+          if (i + 3 < nt) {
+            if ((i + 3) & 1) issue(t0 + i + 3, regB, okB); else issue(t0 + i + 3, regA, okA);
+          }
+        }
+        __syncthreads();
+      }
     }
   } else {
     // =========================== consumer waves ===========================
