@@ -1747,7 +1747,11 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
     const float* nscale = (o.drop_ch >= 0) ? (c->masks + (size_t)N * o.drop_ch) : nullptr;
     float* dYj = c->dyblk[(size_t)j];
     RLN_TRY(finalize_grad_range(c, o.dst_level, o.out_off, o.cout, nscale, &rows, s, dYj));
-    RLN_TRY(reduce_rows(c->bpartial, rows, o.cout, c->grads + o.conv.b, s));
+    // the layer's three small reductions (bias rows, weight slabs, BatchNorm-backward sums of its new-channel data
+    // gradient) run as ONE launch at the end of the iteration when the weight gradient went through d3_wgrad_k
+    DenseTail tail;
+    memset(&tail, 0, sizeof(tail));
+    bool use_tail = false;
     {  // weight gradient of layer j
       WgradParams w;
       memset(&w, 0, sizeof(w));
@@ -1793,9 +1797,17 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
           ProfScope ps(c, PC_D3_WGRAD, wflops, wbytes, s);
           RLN_TRY(d3_wgrad_launch(g, wgrad_parts(c, (long long)N * lv.H * lv.W), c->d3_bwd_dt, s));
         }
-        ProfScope ps2(c, PC_REDUCE, 0, 4.0 * (g.nranges + 1) * w.wsize, s);
-        RLN_TRY(reduce_rows(c->wpartial, g.nranges, w.wsize, c->grads + o.conv.w, s));
+        use_tail = true;
+        tail.w_src = c->wpartial;
+        tail.w_rows = g.nranges;
+        tail.w_len = w.wsize;
+        tail.w_dst = c->grads + o.conv.w;
+        tail.b_src = c->bpartial;
+        tail.b_rows = rows;
+        tail.b_len = o.cout;
+        tail.b_dst = c->grads + o.conv.b;
       } else {
+        RLN_TRY(reduce_rows(c->bpartial, rows, o.cout, c->grads + o.conv.b, s));
         RLN_TRY(run_wgrad(c, WG_DENSE3, w, o.cout, o.cin, o.conv.w, s));
       }
     }
@@ -1849,9 +1861,24 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
           RLN_TRY(igemm_launch(IG_DGRAD3, tile, p, N, s));
         }
       }
-      ProfScope psb(c, PC_BN, 0, 0, s);
-      RLN_TRY(bn_bwd_finalize(c->stat_partial, igemm_stat_blocks(p, N), Jn, c->params + o.bn.gamma + C0,
-                              c->grads + o.bn.gamma + C0, c->grads + o.bn.beta + C0, c->S1 + so, c->S2 + so, s));
+      if (use_tail) {
+        tail.bn_partial = c->stat_partial;
+        tail.bn_rows = igemm_stat_blocks(p, N);
+        tail.J = Jn;
+        tail.gamma = c->params + o.bn.gamma + C0;
+        tail.dgamma = c->grads + o.bn.gamma + C0;
+        tail.dbeta = c->grads + o.bn.beta + C0;
+        tail.S1 = c->S1 + so;
+        tail.S2 = c->S2 + so;
+      } else {
+        ProfScope psb(c, PC_BN, 0, 0, s);
+        RLN_TRY(bn_bwd_finalize(c->stat_partial, igemm_stat_blocks(p, N), Jn, c->params + o.bn.gamma + C0,
+                                c->grads + o.bn.gamma + C0, c->grads + o.bn.beta + C0, c->S1 + so, c->S2 + so, s));
+      }
+    }
+    if (use_tail) {
+      ProfScope pst(c, PC_REDUCE, 0, 4.0 * (tail.w_rows + 1) * tail.w_len, s);
+      RLN_TRY(dense_tail(tail, s));
     }
   }
   // input channels [0, C0): all layers at once (passes of at most D3_LMAX layers)
