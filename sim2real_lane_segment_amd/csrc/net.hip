@@ -1457,7 +1457,6 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
           f.Wd = dl.W;
           ProfScope ps(c, PC_GRADFIN, 0, 12.0 * N * o.cout * dplane, s);
           RLN_TRY(grad_finalize(f, N, &rows, s));
-          RLN_TRY(reduce_rows(c->bpartial, rows, o.cout, c->grads + o.conv.b, s));
         }
         p1_dgrad_plan(&q, c->d3_bwd_np);
         {
@@ -1466,8 +1465,6 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
           ProfScope ps(c, PC_TD_DGRAD, flops, bytes, s);
           RLN_TRY(p1_dgrad_launch(q, c->d3_bwd_np, c->d3_bwd_dt, s));
         }
-        RLN_TRY(bn_bwd_finalize(c->stat_partial, q.bpg, o.cin, c->params + o.bn.gamma, c->grads + o.bn.gamma,
-                                c->grads + o.bn.beta, c->S1 + so, c->S2 + so, s));
         p1_wgrad_plan(&g);
         RLN_TRY(wg_begin(c, s, &ws));
         {
@@ -1476,10 +1473,27 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
           ProfScope ps(c, PC_TD_WGRAD, flops, bytes, ws);
           RLN_TRY(p1_wgrad_launch(g, c->d3_bwd_np, c->d3_bwd_dt, ws));
         }
-        {
-          const long long wsize = (long long)o.cout * o.cin;
-          ProfScope ps2(c, PC_REDUCE, 0, 4.0 * (g.nranges + 1) * wsize, ws);
-          RLN_TRY(reduce_rows(c->wpartial, g.nranges, wsize, c->grads + o.conv.w, ws));
+        {  // bias rows, BatchNorm-backward sums and weight slabs in one launch
+          DenseTail tail;
+          memset(&tail, 0, sizeof(tail));
+          tail.bn_partial = c->stat_partial;
+          tail.bn_rows = q.bpg;
+          tail.J = o.cin;
+          tail.gamma = c->params + o.bn.gamma;
+          tail.dgamma = c->grads + o.bn.gamma;
+          tail.dbeta = c->grads + o.bn.beta;
+          tail.S1 = c->S1 + so;
+          tail.S2 = c->S2 + so;
+          tail.w_src = c->wpartial;
+          tail.w_rows = g.nranges;
+          tail.w_len = (long long)o.cout * o.cin;
+          tail.w_dst = c->grads + o.conv.w;
+          tail.b_src = c->bpartial;
+          tail.b_rows = rows;
+          tail.b_len = o.cout;
+          tail.b_dst = c->grads + o.conv.b;
+          ProfScope ps2(c, PC_REDUCE, 0, 4.0 * (g.nranges + 1) * tail.w_len, ws);
+          RLN_TRY(dense_tail(tail, ws));
         }
         RLN_TRY(wg_end(c));
         return 0;
