@@ -1597,7 +1597,7 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
     const Level& dl = c->levels[o.dst_level];
     const size_t splane = (size_t)sl.H * sl.W, dplane = (size_t)dl.H * dl.W;
     RLN_TRY(finalize_grad_range(c, o.dst_level, 0, o.cout, nullptr, &rows, s));
-    RLN_TRY(reduce_rows(c->bpartial, rows, o.cout, c->grads + o.conv.b, s));
+    // (the bias rows are reduced together with the weight slabs below)
     IgemmParams p;
     memset(&p, 0, sizeof(p));
     p.in = c->dY;  // dU [N][cout][H][W]
@@ -1683,14 +1683,24 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
           RLN_TRY(c3_wgrad_launch(g, c->d3_bwd_np, c->d3_bwd_dt, ws));
         }
         {
-          const long long wsize = (long long)o.cin * o.cout * 9;
-          ProfScope ps2(c, PC_REDUCE, 0, 4.0 * (g.nranges + 1) * wsize, ws);
-          RLN_TRY(reduce_rows(c->wpartial, g.nranges, wsize, c->grads + o.conv.w, ws));
+          DenseTail tail;
+          memset(&tail, 0, sizeof(tail));
+          tail.w_src = c->wpartial;
+          tail.w_rows = g.nranges;
+          tail.w_len = (long long)o.cin * o.cout * 9;
+          tail.w_dst = c->grads + o.conv.w;
+          tail.b_src = c->bpartial;
+          tail.b_rows = rows;
+          tail.b_len = o.cout;
+          tail.b_dst = c->grads + o.conv.b;
+          ProfScope ps2(c, PC_REDUCE, 0, 4.0 * (g.nranges + 1) * tail.w_len, ws);
+          RLN_TRY(dense_tail(tail, ws));
         }
         RLN_TRY(wg_end(c));
         return 0;
       }
     }
+    RLN_TRY(reduce_rows(c->bpartial, rows, o.cout, c->grads + o.conv.b, s));
     WgradParams w;
     memset(&w, 0, sizeof(w));
     w.u = sl.S + (size_t)o.in_off * splane;  // convT input (raw)
