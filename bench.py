@@ -255,15 +255,15 @@ def main():
         def __init__(self, module):
             self.module = module
             (self.opt,), _ = module.configure_optimizers()
+            if world > 1 or args.force_dist:
+                # loss.backward() itself all-reduces finished gradient buckets on a side stream while the remaining
+                # backward runs and hands autograd the mean over ranks (owner.EngineOwner.enable_grad_allreduce)
+                module.enable_grad_allreduce(args.buckets, force_collectives=args.force_dist)
 
         def step(self, x, y):
             self.opt.zero_grad(set_to_none=True)
             loss = self.module.training_step((x, y), 0)
             loss.backward()
-            if world > 1:  # un-overlapped mean over ranks of the flat gradient the backward handed to autograd
-                flat = self.opt.param_groups[0]["params"][0].grad._base
-                dist.all_reduce(flat)
-                flat.mul_(1.0 / world)
             self.opt.step()
             return loss.detach().reshape(1)
 

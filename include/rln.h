@@ -156,6 +156,14 @@ int rln_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t
 int rln_backward_segments(const rln_ctx* ctx);
 int rln_backward_segment_range(const rln_ctx* ctx, int seg, int64_t* grad_begin, int64_t* grad_end);
 int rln_backward(rln_ctx* ctx, float loss_scale, int seg_begin, int seg_end, void* stream);
+/* The same with d(loss) additionally multiplied by a DEVICE scalar (may be NULL): the incoming gradient of
+ * loss.backward() (trainingModules/SimpleTrain.py:25 returns the loss to Lightning, which calls backward on it) never
+ * has to visit the host.  The effective scale is loss_scale * (*loss_scale_dev). */
+int rln_backward_scaled(rln_ctx* ctx, float loss_scale, const float* loss_scale_dev, int seg_begin, int seg_end,
+                        void* stream);
+/* Re-points the gradient arena only (same layout as in rln_bind_params): the module path hands every backward a fresh
+ * flat buffer that autograd then owns, instead of copying out of a fixed arena. */
+int rln_bind_grads(rln_ctx* ctx, float* grads);
 
 /* ---- optimiser: torch.optim.AdamW single group as configured in SimpleTrain.py:27-28, on flat arenas. */
 int rln_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t count, float lr,

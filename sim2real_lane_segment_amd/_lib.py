@@ -55,6 +55,8 @@ _PROTOS = {
     "rln_backward_segments": (c_int, [c_void_p]),
     "rln_backward_segment_range": (c_int, [c_void_p, c_int, POINTER(c_int64), POINTER(c_int64)]),
     "rln_backward": (c_int, [c_void_p, c_float, c_int, c_int, c_void_p]),
+    "rln_backward_scaled": (c_int, [c_void_p, c_float, c_void_p, c_int, c_int, c_void_p]),
+    "rln_bind_grads": (c_int, [c_void_p, c_void_p]),
     "rln_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                                c_float, c_int, c_float, c_void_p]),
     "rln_op_conv_bnrelu": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,

@@ -2216,7 +2216,18 @@ int rln_backward_segment_range(const rln_ctx* c, int seg, int64_t* b, int64_t* e
   return 0;
 }
 
+int rln_bind_grads(rln_ctx* c, float* grads) {
+  if (!grads) return fail(RLN_ERR_ARG, "null gradient arena");
+  c->grads = grads;
+  return 0;
+}
+
 int rln_backward(rln_ctx* c, float loss_scale, int seg_begin, int seg_end, void* stream) {
+  return rln_backward_scaled(c, loss_scale, nullptr, seg_begin, seg_end, stream);
+}
+
+int rln_backward_scaled(rln_ctx* c, float loss_scale, const float* loss_scale_dev, int seg_begin, int seg_end,
+                        void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!c->with_bwd || !c->grads) return fail(RLN_ERR_STATE, "no gradient arena / backward workspace");
   if (!c->have_train_fwd || !c->have_loss)
@@ -2248,6 +2259,7 @@ int rln_backward(rln_ctx* c, float loss_scale, int seg_begin, int seg_end, void*
     q.y = (const long long*)c->last_y;
     q.lossres = c->loss.result;
     q.loss_scale = loss_scale;
+    q.loss_scale_dev = loss_scale_dev;
     q.G = c->levels[0].G;
     q.g_ns = q.h.ns;
     q.invstd = c->invstd + c->levels[0].stat_off;

@@ -102,6 +102,7 @@ struct HeadBwdParams {
   const long long* y;
   const float* lossres;  // LossScratch.result
   float loss_scale;
+  const float* loss_scale_dev;  // optional device scalar multiplied on top (d(loss) handed in by autograd)
   float* G;              // gradient view [N][C][HW] (written: gx / invstd)
   long long g_ns;
   const float* invstd;   // [C]

@@ -635,6 +635,7 @@ int loss_forward(const float* probs, const long long* y, int N, int ncls, int HW
 
 template <int NC>
 __global__ __launch_bounds__(256) void head_bwd_data_k(const HeadBwdParams q) {
+  const float ls = q.loss_scale * (q.loss_scale_dev ? *q.loss_scale_dev : 1.f);  // d(loss) from autograd stays on the device
   const HeadParams& p = q.h;
   extern __shared__ __align__(16) float hsm[];
   float* wt = hsm;
@@ -679,7 +680,7 @@ __global__ __launch_bounds__(256) void head_bwd_data_k(const HeadBwdParams q) {
       const long long lab = q.y[(long long)n * p.HW + px];
       float wy = 0.f;
       if (lab >= 0 && lab < p.ncls) wy = q.lossres[4 + (int)lab];
-      const float coef = q.loss_scale * wy / q.lossres[1];
+      const float coef = ls * wy / q.lossres[1];
 #pragma unroll
       for (int k = 0; k < NC; ++k) {
         gp[k] = (k < p.ncls) ? coef * (qq[k] - ((k == (int)lab) ? 1.f : 0.f)) : 0.f;
@@ -688,11 +689,11 @@ __global__ __launch_bounds__(256) void head_bwd_data_k(const HeadBwdParams q) {
     } else if (q.mode == 2) {  // caller-supplied d(loss)/d(probabilities): differentiable module forward
 #pragma unroll
       for (int k = 0; k < NC; ++k) {
-        gp[k] = (k < p.ncls) ? q.loss_scale * q.gext[((long long)n * p.ncls + k) * p.HW + px] : 0.f;
+        gp[k] = (k < p.ncls) ? ls * q.gext[((long long)n * p.ncls + k) * p.HW + px] : 0.f;
         dot = fmaf(pr[k], gp[k], dot);
       }
     } else {  // d/dp of lamda * mean(sum_k p*log(p+1e-5))
-      const float coef = q.loss_scale * q.lamda * q.inv_count;
+      const float coef = ls * q.lamda * q.inv_count;
 #pragma unroll
       for (int k = 0; k < NC; ++k) {
         gp[k] = (k < p.ncls) ? coef * (logf(pr[k] + 1e-5f) + pr[k] / (pr[k] + 1e-5f)) : 0.f;
@@ -802,6 +803,7 @@ constexpr int HEAD_XS = 33;    // LDS row stride of the staged tile (odd: confli
 
 template <int NC>
 __global__ __launch_bounds__(256) void head_bwd_fused_k(const HeadBwdParams q, float* __restrict__ wpartial) {
+  const float ls = q.loss_scale * (q.loss_scale_dev ? *q.loss_scale_dev : 1.f);  // d(loss) from autograd stays on the device
   const HeadParams& p = q.h;
   extern __shared__ __align__(16) float hsm[];
   float* wt = hsm;                                  // [C][NC]
@@ -867,7 +869,7 @@ __global__ __launch_bounds__(256) void head_bwd_fused_k(const HeadBwdParams q, f
       const long long lab = q.y[(long long)n * p.HW + pxs];
       float wy = 0.f;
       if (lab >= 0 && lab < p.ncls) wy = q.lossres[4 + (int)lab];
-      const float coef = q.loss_scale * wy / q.lossres[1];
+      const float coef = ls * wy / q.lossres[1];
 #pragma unroll
       for (int k = 0; k < NC; ++k) {
         gp[k] = (k < p.ncls) ? coef * (qq[k] - ((k == (int)lab) ? 1.f : 0.f)) : 0.f;
@@ -876,11 +878,11 @@ __global__ __launch_bounds__(256) void head_bwd_fused_k(const HeadBwdParams q, f
     } else if (q.mode == 2) {  // caller-supplied d(loss)/d(probabilities): differentiable module forward
 #pragma unroll
       for (int k = 0; k < NC; ++k) {
-        gp[k] = (k < p.ncls) ? q.loss_scale * q.gext[((long long)n * p.ncls + k) * p.HW + pxs] : 0.f;
+        gp[k] = (k < p.ncls) ? ls * q.gext[((long long)n * p.ncls + k) * p.HW + pxs] : 0.f;
         dot = fmaf(pr[k], gp[k], dot);
       }
     } else {  // d/dp of lamda * mean(sum_k p*log(p+1e-5))
-      const float coef = q.loss_scale * q.lamda * q.inv_count;
+      const float coef = ls * q.lamda * q.inv_count;
 #pragma unroll
       for (int k = 0; k < NC; ++k) {
         gp[k] = (k < p.ncls) ? coef * (logf(pr[k] + 1e-5f) + pr[k] / (pr[k] + 1e-5f)) : 0.f;

@@ -113,7 +113,8 @@ class Engine:
         self.device = torch.device("cpu")
         self.params = self.grads = self.bnrun = self.nbt = None
         self.views: Dict[str, torch.Tensor] = {}
-        self.grad_views: Dict[str, torch.Tensor] = {}
+        self._grad_views: Dict[str, torch.Tensor] = {}
+        self._grad_views_of = None
         self._ws = None
         self._ws_key = None
         self._keep = []
@@ -147,11 +148,11 @@ class Engine:
             self.bnrun.copy_(prev[1])
             self.nbt.copy_(prev[2])
         self.device = device
-        self.views, self.grad_views = {}, {}
+        self.views = {}
+        self._grad_views_of = None
         for m in self.metas:
             if m.kind == _lib.T_PARAM:
                 self.views[m.name] = self.params[m.offset:m.offset + m.numel].view(m.shape)
-                self.grad_views[m.name] = self.grads[m.offset:m.offset + m.numel].view(m.shape)
             elif m.kind in (_lib.T_RUNNING_MEAN, _lib.T_RUNNING_VAR):
                 self.views[m.name] = self.bnrun[m.offset:m.offset + m.numel].view(m.shape)
             else:
@@ -161,6 +162,27 @@ class Engine:
         if device.type == "cuda":
             _lib.check(self.L.rln_bind_params(self.ctx, _ptr(self.params), _ptr(self.grads), _ptr(self.bnrun),
                                               _ptr(self.nbt)), "rln_bind_params")
+
+    @property
+    def grad_views(self) -> Dict[str, torch.Tensor]:
+        """Views of the engine's own gradient arena under the reference's parameter names."""
+        if self._grad_views_of is not self.grads:
+            self._grad_views = {m.name: self.grads[m.offset:m.offset + m.numel].view(m.shape)
+                                for m in self.metas if m.kind == _lib.T_PARAM}
+            self._grad_views_of = self.grads
+        return self._grad_views
+
+    def bind_grads(self, flat: Optional[torch.Tensor]):
+        """Makes ``flat`` (fp32, n_param elements, on the engine's device) the gradient arena of the backward calls
+        that follow (rln_bind_grads); None re-binds the engine's own arena ``self.grads``.  The module path binds a
+        fresh buffer around every backward (autograd then owns it) and re-binds the own arena right after."""
+        self._require_gpu()
+        if flat is None:
+            flat = self.grads
+        if flat.dtype != torch.float32 or flat.numel() != self.n_param or flat.device != self.device or \
+                not flat.is_contiguous():
+            raise RuntimeError("gradient arena must be a contiguous fp32 tensor of n_param elements on the engine's device")
+        _lib.check(self.L.rln_bind_grads(self.ctx, _ptr(flat)), "rln_bind_grads")
 
     def load_state(self, state: Dict[str, torch.Tensor]):
         for m in self.metas:
@@ -275,11 +297,19 @@ class Engine:
                                        float(momentum), float(weight_decay), int(first_step), float(grad_scale),
                                        _stream()), "rln_sgd_step")
 
-    def backward(self, loss_scale: float = 1.0, seg_begin: int = 0, seg_end: Optional[int] = None):
+    def backward(self, loss_scale: float = 1.0, seg_begin: int = 0, seg_end: Optional[int] = None,
+                 loss_scale_dev: Optional[torch.Tensor] = None):
+        """loss_scale_dev: optional device scalar multiplied on top of loss_scale inside the head-backward kernel
+        (rln_backward_scaled): the d(loss) autograd hands to loss.backward() never visits the host."""
         self._require_gpu()
         if seg_end is None:
             seg_end = self.n_seg
-        _lib.check(self.L.rln_backward(self.ctx, float(loss_scale), seg_begin, seg_end, _stream()), "rln_backward")
+        if loss_scale_dev is not None:
+            if loss_scale_dev.dtype != torch.float32 or loss_scale_dev.device != self.device:
+                loss_scale_dev = loss_scale_dev.to(device=self.device, dtype=torch.float32)
+            self._keep.append(loss_scale_dev)
+        _lib.check(self.L.rln_backward_scaled(self.ctx, float(loss_scale), _ptr(loss_scale_dev), seg_begin, seg_end,
+                                              _stream()), "rln_backward_scaled")
 
     def adamw_step(self, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
                    grad_scale=1.0, lo=0, hi=None):

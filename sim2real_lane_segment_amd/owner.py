@@ -30,6 +30,38 @@ class EngineOwner:
     _rln_engine: Optional[Engine] = None
     _rln_dirty: bool = True
     _rln_dummy_classifier = None
+    _rln_reducer = None
+
+    def enable_grad_allreduce(self, n_buckets: int = 4, group=None, force_collectives: bool = False):
+        """Data-parallel training through the module path (what Lightning drives: training_step -> loss.backward() ->
+        optimizer.step(), train.py:63-64): every backward of this module runs its segments bucket by bucket and
+        all-reduces each finished slice of the flat gradient buffer on a side stream while the remaining backward
+        runs (trainer.BucketedGradReducer); autograd receives the MEAN over ranks, as torch DDP would deliver it.
+        Call once after torch.distributed.init_process_group; do not wrap the module in DistributedDataParallel as
+        well (the gradients would be reduced twice)."""
+        from .trainer import BucketedGradReducer
+        eng = self._rln_sync()
+        object.__setattr__(self, "_rln_reducer",
+                           BucketedGradReducer(eng.grads, eng.seg_ranges, n_buckets, group=group,
+                                               force_collectives=force_collectives))
+        return self._rln_reducer
+
+    def _rln_backward_into_fresh_arena(self, eng, g_scale):
+        """One backward into a fresh flat buffer that autograd then owns (AccumulateGrad may keep or add into the
+        views): no copy out of a fixed arena, d(loss) applied inside the head-backward kernel from its device scalar."""
+        flat = torch.empty_like(eng.params)
+        eng.bind_grads(flat)
+        try:
+            red = self._rln_reducer
+            if red is not None and (red.world > 1 or red.force):
+                inv = 1.0 / red.world  # the all-reduce sums: scaling d(loss) by 1/world delivers the mean
+                red.backward_and_reduce(lambda sb, se: eng.backward(inv, sb, se, loss_scale_dev=g_scale), flat=flat)
+            else:
+                eng.backward(1.0, loss_scale_dev=g_scale)
+        finally:
+            eng.bind_grads(None)  # kernel arguments are baked at enqueue time: the own arena is current again
+        return tuple(flat[m.offset:m.offset + m.numel].view(m.shape) for m in eng.metas
+                     if m.kind == _lib.T_PARAM and m.name in self._rln_param_set)
 
     def _rln_spec(self) -> NetSpec:
         fe = self.featureExtractor
@@ -111,6 +143,9 @@ class TrainStepFn(torch.autograd.Function):
     def forward(ctx, owner, x, y, drop_scales, seed, *params):
         """y: int64 labels -> class-weighted CE step; y: float lamda -> MME unlabelled step (entropy of the
         classifier output behind a gradient-reversal layer, MMETrainingModule.py:28-33)."""
+        if x.requires_grad:
+            raise RuntimeError("the fused training step does not produce a gradient with respect to its input image "
+                               "(x.requires_grad is set): detach the input")
         eng = owner._rln_sync()
         probs, _ = eng.forward(x, training=True, with_backward=True, drop_scales=drop_scales, seed=seed)
         if isinstance(y, float):
@@ -130,15 +165,9 @@ class TrainStepFn(torch.autograd.Function):
         owner = ctx.owner
         eng = owner._rln_engine
         _check_token(eng, ctx.token)
-        eng.backward(1.0)
-        # hand autograd a private flat copy (AccumulateGrad may keep or add into these tensors), scaled by the
-        # incoming d(loss); FusedAdamW recognises the flat layout and consumes it with one kernel.
-        flat = eng.grads * g_loss
-        grads = []
-        for m in eng.metas:
-            if m.kind == _lib.T_PARAM and m.name in owner._rln_param_set:
-                grads.append(flat[m.offset:m.offset + m.numel].view(m.shape))
-        return (None, None, None, None, None) + tuple(grads)
+        # autograd receives slices of ONE fresh flat buffer (FusedAdamW recognises the layout and consumes it with one
+        # kernel); with enable_grad_allreduce() the slices are all-reduced while the rest of the backward runs
+        return (None, None, None, None, None) + owner._rln_backward_into_fresh_arena(eng, g_loss)
 
 
 def _check_token(eng, token):
@@ -150,15 +179,6 @@ def _check_token(eng, token):
                            "separate modules")
 
 
-def _flat_param_grads(owner, eng, scale=None):
-    flat = eng.grads * scale if scale is not None else eng.grads.clone()
-    grads = []
-    for m in eng.metas:
-        if m.kind == _lib.T_PARAM and m.name in owner._rln_param_set:
-            grads.append(flat[m.offset:m.offset + m.numel].view(m.shape))
-    return tuple(grads)
-
-
 class ForwardFn(torch.autograd.Function):
     """Differentiable ``forward`` of the fused net (train mode): probabilities out, d(loss)/d(probabilities) in
     (TrainingBase.forward used inside user-written steps: SimpleTrain.py:15, MMETrainingModule.py:34-35).  The gradient
@@ -166,6 +186,9 @@ class ForwardFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, owner, x, drop_scales, seed, *params):
+        if x.requires_grad:
+            raise RuntimeError("the fused forward does not produce a gradient with respect to its input image "
+                               "(x.requires_grad is set): detach the input")
         eng = owner._rln_sync()
         probs, _ = eng.forward(x, training=True, with_backward=True, drop_scales=drop_scales, seed=seed)
         ctx.owner = owner
@@ -178,8 +201,7 @@ class ForwardFn(torch.autograd.Function):
         eng = owner._rln_engine
         _check_token(eng, ctx.token)
         eng.set_output_grad(g_probs)
-        eng.backward(1.0)
-        return (None, None, None, None) + _flat_param_grads(owner, eng)
+        return (None, None, None, None) + owner._rln_backward_into_fresh_arena(eng, None)
 
 
 class FusedAdamW(torch.optim.Optimizer):

@@ -45,14 +45,17 @@ class BucketedGradReducer:
         self.cuda = flat_grads.is_cuda
         self.comm_stream = torch.cuda.Stream(device=flat_grads.device) if self.cuda else None
 
-    def backward_and_reduce(self, run_segments: Callable[[int, int], None]):
+    def backward_and_reduce(self, run_segments: Callable[[int, int], None], flat: Optional[torch.Tensor] = None):
+        """flat: the gradient buffer of THIS backward when it is not the one given at construction (the module path
+        hands every backward a fresh buffer)."""
+        flat = self.flat if flat is None else flat
         if self.world == 1 and not self.force:
             run_segments(0, self.buckets[-1][1])
             return
         handles = []
         for (sb, se, gb, ge) in self.buckets:
             run_segments(sb, se)
-            view = self.flat[gb:ge]
+            view = flat[gb:ge]
             if self.cuda:
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream())

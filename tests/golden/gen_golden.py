@@ -225,9 +225,11 @@ def gen_fcd67_train(name, n, h, w, seed, steps):
         mod.zero_grad()
         loss.backward()
         if s == 0:
+            # per tensor: L2 norm, sum, and up to 1024 sampled entries (tensors with <= 1024 elements are stored whole):
+            # the tests estimate the L2-relative error of every tensor and of the whole arena from these
             for k, p in named.items():
                 g = p.grad.detach()
-                idx = sample_idx(g.numel(), 64, 1234)
+                idx = sample_idx(g.numel(), 1024, 1234)
                 out["gradnorm/" + k] = np.float32(g.norm().item())
                 out["gradsum/" + k] = np.float32(g.double().sum().item())
                 out["gradsamp/" + k] = g.reshape(-1)[idx].numpy().copy()
@@ -424,7 +426,7 @@ def main():
     if "fcd67_eval480" in which:
         gen_fcd67_eval("fcd67_eval_480x640", 1, 480, 640, 600)
     if "fcd67_train" in which:
-        gen_fcd67_train("fcd67_train_120x160", 2, 120, 160, 700, steps=3)
+        gen_fcd67_train("fcd67_train_120x160", 2, 120, 160, 700, steps=5)
 
 
 if __name__ == "__main__":

@@ -149,3 +149,23 @@ def test_metrics_match_oracle_definitions():
     pred2 = torch.clamp(pred, max=2)  # class 3 absent from both -> inferred num_classes shrinks
     cm2 = metrics.confusion_matrix(pred2, target, 4)
     assert float(metrics.iou_from_confusion(cm2)) == pytest.approx(float(O.iou(pred2, target)), rel=1e-6)
+
+
+def test_two_domain_synthetic_batches():
+    """BASELINE.json configs[4] workload: the 50/50 source/target mix of TwoDomainDM.train_dataloader
+    (dataManagement/dataModules.py:79-85) on synthetic frames of two looks."""
+    from sim2real_lane_segment_amd import synthetic as S
+    idx, dom = S.two_domain_indices(1000, 100, 20000, 3)
+    assert abs(float(dom.float().mean()) - 0.5) < 0.02          # each DOMAIN with probability 1/2, whatever the set sizes
+    assert int(idx[dom == 0].max()) < 1000 <= int(idx[dom == 1].min())
+    x, y, d = S.make_two_domain_batch(8, 64, 96, seed=5)
+    x2, y2, d2 = S.make_two_domain_batch(8, 64, 96, seed=5)
+    assert torch.equal(x, x2) and torch.equal(y, y2) and torch.equal(d, d2)
+    assert x.shape == (8, 3, 64, 96) and y.shape == (8, 64, 96) and y.dtype == torch.int64
+    assert 0 < int(d.sum()) < 8 and int(y.max()) <= 3
+    # the two looks have different first-order statistics (darker, greyer target frames)
+    assert float(x[d == 1].mean()) < float(x[d == 0].mean()) - 0.1
+    # a sample of domain 0 is the plain simulator frame of the same index
+    i0 = int(torch.nonzero(d == 0)[0])
+    xs, ys = S.make_batch(1, 64, 96, seed=5, first_index=int(S.two_domain_indices(1000, 100, 8, 5)[0][i0]))
+    assert torch.equal(xs[0], x[i0]) and torch.equal(ys[0], y[i0])

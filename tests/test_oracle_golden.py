@@ -130,3 +130,41 @@ def test_mme_unlabelled_step_and_sgd():
             lr = 1e-3 if k.startswith("classifier.") else 1e-3 / 3
             bufs[k] = O.sgd_nesterov_step(st[k], torch.from_numpy(z["grad0/" + k]), bufs.get(k), lr, 0.9, 1e-4)
             np.testing.assert_allclose(st[k].numpy(), z[key + k], rtol=1e-5, atol=1e-7, err_msg=k)
+
+
+def test_fcd67_five_training_steps_vs_reference_fixture():
+    """The oracle's training step against the reference's own SimpleTrainModule.training_step + AdamW over FIVE steps of
+    FCDenseNet67 (fixture fcd67_train_120x160, generated by tests/golden/gen_golden.py from the reference's classes):
+    loss / accuracy trajectory, step-0 gradients (norm and up to 1024 sampled entries per tensor), step-0 parameters and
+    running statistics."""
+    z = load("fcd67_train_120x160")
+    cfg = cfg_from_arrays(z, O.NetConfig)
+    n, h, w, seed, steps = int(z["n"]), int(z["h"]), int(z["w"]), int(z["seed"]), int(z["steps"])
+    assert steps == 5
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    ts = O.TrainState(O.init_state(cfg, seed))
+    for s in range(steps):
+        x, y = synth_batch(n, h, w, 4, seed + 10 * s + 1)
+        if s == 0:
+            y[0][y[0] == 3] = 0
+        scales = O.make_drop_scales(cfg, n, seed + 10 * s + 2)
+        loss, acc, grads, _ = O.train_step(ts, x, y, cfg, scales, lr=1e-3, weight_decay=1e-4)
+        assert abs(float(loss) - float(z["losses"][s])) < 2e-5, (s, float(loss), float(z["losses"][s]))
+        assert abs(float(acc) - float(z["accs"][s])) < 2e-3
+        if s == 0:
+            num = den = 0.0
+            for k, g in grads.items():
+                idx = sample_idx(g.numel(), 1024, 1234)
+                ref = z["gradsamp/" + k]
+                nrm = float(z["gradnorm/" + k])
+                got = g.reshape(-1)[idx].numpy()
+                d2 = float(((got.astype(np.float64) - ref) ** 2).sum()) * g.numel() / len(idx)
+                num += d2
+                den += nrm * nrm
+                # same algorithm, same operators, possibly another thread count: fp32 summation-order noise only
+                assert np.sqrt(d2) <= 3e-3 * nrm + 1e-6 * np.sqrt(g.numel()), k
+                assert abs(float(g.norm()) - nrm) <= 1e-3 * nrm + 1e-9, k
+            assert np.sqrt(num / den) < 2e-4
+            for k in z.files:
+                if k.startswith("buf1/"):
+                    np.testing.assert_allclose(ts.st[k[5:]].numpy(), z[k], rtol=1e-5, atol=1e-6)
