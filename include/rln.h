@@ -98,6 +98,18 @@ int rln_set_dense_arith(rln_ctx* ctx, int fwd_parts, int fwd_dtype, int bwd_part
  * resets it to 1 for two-part backward arithmetic and to bwd_parts otherwise; 0 = bwd_parts. */
 int rln_set_wgrad_parts(rln_ctx* ctx, int parts);
 
+int rln_get_wgrad_parts(const rln_ctx* ctx);
+/* Storage element type of the activation stacks and of the finalised output gradients in HBM (csrc/storage.h).
+ *   0 : fp32 everywhere (default; the parity mode of BASELINE.json's north_star);
+ *   1 : bf16 on the resolution levels the 16-bit kernel families cover (rows of >= 40 pixels in whole octets: 97.5 % of
+ *       the activation elements at 120x160), fp32 on the deep levels.  Matches the reference's mixed-precision runs
+ *       (Lightning --precision 16, train.py:100-101; BASELINE.json configs[1], [3]).  Operands are plain bf16 (forces
+ *       rln_set_dense_arith(1, bf16, 1, bf16)); BatchNorm statistics, accumulation, the gradient stacks, parameters,
+ *       the head's probabilities and every reduction stay fp32; values are rounded to nearest-even once, when stored.
+ * Call before rln_workspace_bytes.  Input / output tensors of the ABI stay fp32. */
+int rln_set_storage(rln_ctx* ctx, int mode);
+int rln_get_storage(const rln_ctx* ctx);
+
 int rln_bind_params(rln_ctx* ctx, float* params, float* grads, float* bn_running, int64_t* num_batches_tracked);
 
 /* ---- workspace -------------------------------------------------------------------------

@@ -81,6 +81,9 @@ _PROTOS = {
                                 c_size_t, c_void_p]),
     "rln_set_dense_arith": (c_int, [c_void_p, c_int, c_int, c_int, c_int]),
     "rln_set_wgrad_parts": (c_int, [c_void_p, c_int]),
+    "rln_get_wgrad_parts": (c_int, [c_void_p]),
+    "rln_set_storage": (c_int, [c_void_p, c_int]),
+    "rln_get_storage": (c_int, [c_void_p]),
     "rln_op_convt": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
                              c_int, c_int, c_void_p]),
     "rln_profile_enable": (c_int, [c_void_p, c_int]),

@@ -54,6 +54,7 @@ struct C3Fwd {
   int out_cs, Cout, Ho, Wo;
   float* stat_partial;  // [bpg][Cout][2] (sum, sum of squares of what was written) or null
   int mt, groups, bpg;
+  int st, ot;  // storage element types of X and of out (storage.h)
 };
 bool c3_fwd_supported(const C3Fwd& p);
 bool c3_fwd_fits(const C3Fwd& p, int np);  // one M tile (9 taps x K steps x parts) fits the LDS budget
@@ -70,6 +71,7 @@ struct C3Dgrad {
   long long ns;
   int cs, H, W, C, N;
   int mt, groups, bpg;  // mt = c3_dgrad_mt(ceil(C/16))
+  int yt;               // storage element type of dU (storage.h); G is fp32
 };
 bool c3_dgrad_supported(const C3Dgrad& p);
 void c3_dgrad_plan(C3Dgrad* p);
@@ -85,6 +87,7 @@ struct C3Wgrad {
   float* partial;  // [nranges][Cin][Cout][9]
   int mo, nc;      // output-channel tiles (<= 2: the block has 3*mo waves) and input-channel tiles (<= 5) per block
   int ogroups, cgroups, nranges, per;  // per = K steps (32 input pixels) per range
+  int st, yt;      // storage element types of X and of dU (storage.h)
 };
 bool c3_wgrad_supported(const C3Wgrad& p);
 void c3_wgrad_plan(C3Wgrad* p);

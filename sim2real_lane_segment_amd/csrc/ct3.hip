@@ -5,6 +5,7 @@
 #include <cstdio>
 
 #include "split16.h"
+#include "storage.h"
 
 namespace rln {
 
@@ -113,7 +114,7 @@ static void c3_group_plan(int m_tiles, int ksteps, int np, int* mt, int* groups)
 //   P10 += W10*own + W12*left                            P11 += W11*own
 // Epilogue: + bias, crop to Ho x Wo, 8-byte stores (rows 2y and 2y+1), per-channel sums for the next BatchNorm.
 // =============================================================================================
-template <int NP, int DT>
+template <int NP, int DT, int XT, int OT>
 __global__ __launch_bounds__(512, 2) void c3_fwd_k(const C3Fwd p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -139,12 +140,13 @@ __global__ __launch_bounds__(512, 2) void c3_fwd_k(const C3Fwd p) {
   const int ntiles = (cells + 14) / 15;
   const int nsuper = (ntiles + 1) >> 1;
   const int sstride = p.bpg * 8;
-  const bool vec2 = ((p.Wo | p.out_cs) & 1) == 0 && (p.out_ns & 1) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 7) == 0;
+  const bool vec2 = ((p.Wo | p.out_cs) & 1) == 0 && (p.out_ns & 1) == 0 &&
+                    (reinterpret_cast<uintptr_t>(p.out) & (2 * SP<OT>::ES - 1)) == 0;
 
   struct Cell {
-    const float* own;
-    const float* up;
-    float* outp;          // out at (sample, channel 0, row 2y, column 2x)
+    SP<XT> own;
+    SP<XT> up;
+    SP<OT> outp;          // out at (sample, channel 0, row 2y, column 2x)
     unsigned left_mask;   // all ones when the lane has a left neighbour in its row
     bool v_own, v_up, valid;
     int oy, ox;
@@ -161,22 +163,22 @@ __global__ __launch_bounds__(512, 2) void c3_fwd_k(const C3Fwd p) {
     c.v_up = inr && y >= 1 && x < p.W;
     c.valid = inr && n16 >= 1;
     c.left_mask = x >= 1 ? 0xFFFFFFFFu : 0u;
-    const float* xb = p.X + (long long)ns_ * p.ns + min(x, p.W - 1);
+    const SP<XT> xb = SP<XT>(p.X) + ((long long)ns_ * p.ns + min(x, p.W - 1));
     c.own = xb + (long long)min(y, p.H - 1) * p.W;
     c.up = xb + (long long)max(min(y, p.H) - 1, 0) * p.W;
     c.oy = 2 * y;
     c.ox = 2 * x;
-    c.outp = p.out + (long long)ns_ * p.out_ns + (long long)c.oy * p.Wo + c.ox;
+    c.outp = SP<OT>(p.out) + ((long long)ns_ * p.out_ns + (long long)c.oy * p.Wo + c.ox);
     return c;
   };
 
-  float ro[2][8], ru[2][8];
+  typename SRaw<XT>::r1 qo[2][8], qu[2][8];  // narrow until convert widens them
   auto issue = [&](const Cell& c, int w, int ks) __attribute__((always_inline)) {
     const long long off = (long long)min(ks * 32 + kb * 8, p.Cin - 8) * p.cs;  // Cin % 8 == 0; weights past Cin are zero
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      ro[w][e] = c.own[off + (long long)e * p.cs];
-      ru[w][e] = c.up[off + (long long)e * p.cs];
+      qo[w][e] = c.own.raw1(off + (long long)e * p.cs);
+      qu[w][e] = c.up.raw1(off + (long long)e * p.cs);
     }
   };
   uint4 fo[2][NP], fu[2][NP], fl[2][NP], ful[2][NP];
@@ -184,8 +186,8 @@ __global__ __launch_bounds__(512, 2) void c3_fwd_k(const C3Fwd p) {
     unsigned a[4][NP], u[4][NP];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      split2<DT, NP>(c.v_own ? ro[w][2 * j] : 0.f, c.v_own ? ro[w][2 * j + 1] : 0.f, a[j]);
-      split2<DT, NP>(c.v_up ? ru[w][2 * j] : 0.f, c.v_up ? ru[w][2 * j + 1] : 0.f, u[j]);
+      split2<DT, NP>(c.v_own ? SRaw<XT>::w1(qo[w][2 * j]) : 0.f, c.v_own ? SRaw<XT>::w1(qo[w][2 * j + 1]) : 0.f, a[j]);
+      split2<DT, NP>(c.v_up ? SRaw<XT>::w1(qu[w][2 * j]) : 0.f, c.v_up ? SRaw<XT>::w1(qu[w][2 * j + 1]) : 0.f, u[j]);
     }
 #pragma unroll
     for (int pt = 0; pt < NP; ++pt) {
@@ -274,17 +276,17 @@ __global__ __launch_bounds__(512, 2) void c3_fwd_k(const C3Fwd p) {
             const bool ov = o < p.Cout;
             float v[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = acc[m][w][q][r] + bia[r];
-            float* dst = c.outp + (long long)o * p.out_cs;
+            for (int q = 0; q < 4; ++q) v[q] = st_round<OT>(acc[m][w][q][r] + bia[r]);  // statistics of the stored tensor
+            const SP<OT> dst = c.outp + (long long)o * p.out_cs;
             const bool m00 = ov && r0v && x0v, m01 = ov && r0v && x1v, m10 = ov && r1v && x0v, m11 = ov && r1v && x1v;
             if (vec2) {  // Wo even: a block column pair is all-in or all-out
-              if (m00) *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[1]);
-              if (m10) *reinterpret_cast<float2*>(dst + p.Wo) = make_float2(v[2], v[3]);
+              if (m00) dst.st2(0, v[0], v[1]);
+              if (m10) dst.st2(p.Wo, v[2], v[3]);
             } else {
-              if (m00) dst[0] = v[0];
-              if (m01) dst[1] = v[1];
-              if (m10) dst[p.Wo] = v[2];
-              if (m11) dst[p.Wo + 1] = v[3];
+              if (m00) dst.st1(0, v[0]);
+              if (m01) dst.st1(1, v[1]);
+              if (m10) dst.st1(p.Wo, v[2]);
+              if (m11) dst.st1(p.Wo + 1, v[3]);
             }
             float s1 = (m00 ? v[0] : 0.f) + (m01 ? v[1] : 0.f) + (m10 ? v[2] : 0.f) + (m11 ? v[3] : 0.f);
             float s2 = (m00 ? v[0] * v[0] : 0.f) + (m01 ? v[1] * v[1] : 0.f) + (m10 ? v[2] * v[2] : 0.f) +
@@ -340,12 +342,12 @@ void c3_fwd_plan(C3Fwd* p, int np) {
   p->bpg = (int)std::max(1ll, std::min((nsuper + 7) / 8, (long long)std::max(1, 256 / p->groups)));
 }
 
-template <int NP, int DT>
+template <int NP, int DT, int ST = ST_F32, int OT = ST_F32>
 static int c3_fwd_launch_t(const C3Fwd& p, hipStream_t s) {
   const int KS = (p.Cin + 31) / 32;
   const size_t lds = (size_t)p.mt * KS * 9 * NP * 1024 + (size_t)p.mt * 16 * 4 + (size_t)8 * p.mt * 32 * 4;
   if (lds > 160 * 1024) return -4;
-  auto kern = c3_fwd_k<NP, DT>;
+  auto kern = c3_fwd_k<NP, DT, ST, OT>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -360,6 +362,12 @@ static int c3_fwd_launch_t(const C3Fwd& p, hipStream_t s) {
 int c3_fwd_launch(const C3Fwd& p, int np, int dt, hipStream_t s) {
   if (!c3_fwd_supported(p) || p.mt < 1 || p.mt > C3_MT || p.groups < 1 || p.bpg < 1) return -4;
   if (p.mt * p.groups * 16 < p.Cout) return -4;
+  if (p.st == ST_BF16 || p.ot == ST_BF16) {  // bf16 storage on either side = plain bf16 operands
+    if (np != 1 || dt != D3_BF16) return -4;
+    if (p.st == ST_BF16 && p.ot == ST_BF16) return c3_fwd_launch_t<1, D3_BF16, ST_BF16, ST_BF16>(p, s);
+    if (p.st == ST_BF16) return c3_fwd_launch_t<1, D3_BF16, ST_BF16, ST_F32>(p, s);
+    return c3_fwd_launch_t<1, D3_BF16, ST_F32, ST_BF16>(p, s);
+  }
   if (dt == D3_BF16) {
     if (np == 1) return c3_fwd_launch_t<1, D3_BF16>(p, s);
     if (np == 2) return c3_fwd_launch_t<2, D3_BF16>(p, s);
@@ -382,7 +390,7 @@ int c3_fwd_launch(const C3Fwd& p, int np, int dt, hipStream_t s) {
 // lane's kx = 0 fragment (DPP) and issue 3 x mt x parts MFMAs per wave tile.  dU is read once per 80 input channels.
 // =============================================================================================
 constexpr int C3_DMT = 5;
-template <int NP, int DT>
+template <int NP, int DT, int YT>
 __global__ __launch_bounds__(512, 2) void c3_dgrad_k(const C3Dgrad p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -405,7 +413,7 @@ __global__ __launch_bounds__(512, 2) void c3_dgrad_k(const C3Dgrad p) {
   const long long oplane = (long long)p.Ho * p.Wo;
 
   struct Cell {
-    const float* du;  // dU at (sample, channel 0, row 2y, column 2x)
+    SP<YT> du;        // dU at (sample, channel 0, row 2y, column 2x)
     float* gp;        // G at (sample, channel 0, y, x)
     unsigned right_mask;
     int y2;
@@ -422,7 +430,7 @@ __global__ __launch_bounds__(512, 2) void c3_dgrad_k(const C3Dgrad p) {
     const int y = rem / p.W, x = rem - y * p.W;
     c.right_mask = (x + 1 < p.W) ? 0xFFFFFFFFu : 0u;
     c.y2 = 2 * y;
-    c.du = p.dU + (long long)ns_ * p.Cout * oplane + 2 * x;
+    c.du = SP<YT>(p.dU) + ((long long)ns_ * p.Cout * oplane + 2 * x);
     c.gp = p.G + (long long)ns_ * p.ns + rem;
     return c;
   };
@@ -454,9 +462,9 @@ __global__ __launch_bounds__(512, 2) void c3_dgrad_k(const C3Dgrad p) {
   auto issue = [&](const Cell& c, int w, int step) __attribute__((always_inline)) {
     const int ks = step / 3, ky = step - ks * 3;
     const int Y = min(c.y2 + ky, p.Ho - 1);
-    const float* q = c.du + (long long)min(ks * 32 + kb * 8, p.Cout - 8) * oplane + (long long)Y * p.Wo;
+    const SP<YT> q = c.du + ((long long)min(ks * 32 + kb * 8, p.Cout - 8) * oplane + (long long)Y * p.Wo);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) raw[w][e] = *reinterpret_cast<const float2*>(q + (long long)e * oplane);
+    for (int e = 0; e < 8; ++e) raw[w][e] = q.ld2((long long)e * oplane);
   };
   uint4 f0[2][NP], f1[2][NP], f2[2][NP];
   auto convert = [&](const Cell& c, int w, int step) __attribute__((always_inline)) {
@@ -549,7 +557,7 @@ __global__ __launch_bounds__(512, 2) void c3_dgrad_k(const C3Dgrad p) {
 bool c3_dgrad_supported(const C3Dgrad& p) {
   if (p.H < 1 || p.W < 1 || p.N < 1 || p.C < 1 || p.Cout < 8 || (p.Cout & 7)) return false;
   if (p.Wo != 2 * p.W || (p.Ho != 2 * p.H && p.Ho != 2 * p.H + 1)) return false;  // 8-byte column pairs: even cropped width
-  if ((reinterpret_cast<uintptr_t>(p.dU) & 7) != 0) return false;
+  if ((reinterpret_cast<uintptr_t>(p.dU) & (p.yt == ST_BF16 ? 3 : 7)) != 0) return false;
   if ((long long)p.N * p.H * p.W + 64 >= (1ll << 31)) return false;
   return true;
 }
@@ -563,11 +571,11 @@ void c3_dgrad_plan(C3Dgrad* p) {
   p->bpg = (int)std::max(1ll, std::min((nsuper + 7) / 8, (long long)std::max(1, 256 / p->groups)));
 }
 
-template <int NP, int DT>
+template <int NP, int DT, int YT = ST_F32>
 static int c3_dgrad_launch_t(const C3Dgrad& p, hipStream_t s) {
   const size_t lds = (size_t)2 * p.mt * 3 * NP * 1024;
   if (lds > 160 * 1024) return -4;
-  auto kern = c3_dgrad_k<NP, DT>;
+  auto kern = c3_dgrad_k<NP, DT, YT>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -582,6 +590,10 @@ static int c3_dgrad_launch_t(const C3Dgrad& p, hipStream_t s) {
 int c3_dgrad_launch(const C3Dgrad& p, int np, int dt, hipStream_t s) {
   if (!c3_dgrad_supported(p) || p.mt < 1 || p.mt > C3_DMT || p.groups < 1 || p.bpg < 1) return -4;
   if (p.mt != c3_dgrad_mt((p.C + 15) / 16) || p.mt * p.groups * 16 < p.C) return -4;
+  if (p.yt == ST_BF16) {  // bf16 storage = plain bf16 operands
+    if (np != 1 || dt != D3_BF16) return -4;
+    return c3_dgrad_launch_t<1, D3_BF16, ST_BF16>(p, s);
+  }
   if (dt == D3_BF16) {
     if (np == 1) return c3_dgrad_launch_t<1, D3_BF16>(p, s);
     if (np == 2) return c3_dgrad_launch_t<2, D3_BF16>(p, s);
@@ -606,7 +618,7 @@ int c3_dgrad_launch(const C3Dgrad& p, int np, int dt, hipStream_t s) {
 // partial[range][c][o][ky][kx] is reduced afterwards in fixed order.
 // =============================================================================================
 constexpr int C3_WNC = 5;
-template <int NP, int DT, int MO>
+template <int NP, int DT, int MO, int ST, int YT>
 __global__ __launch_bounds__(192 * MO, 3) void c3_wgrad_k(const C3Wgrad p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -645,10 +657,10 @@ __global__ __launch_bounds__(192 * MO, 3) void c3_wgrad_k(const C3Wgrad p) {
     const int y = rem / W8, x0 = (rem - y * W8) * 8;
     const int Y = 2 * y + ky;
     a.ok = sg < SG && Y < p.Ho;
-    const float* q = p.dU + ((long long)ns_ * p.Cout + o_lane) * oplane + (long long)min(Y, p.Ho - 1) * p.Wo + 2 * x0;
+    const SP<YT> q = SP<YT>(p.dU) + (((long long)ns_ * p.Cout + o_lane) * oplane + (long long)min(Y, p.Ho - 1) * p.Wo + 2 * x0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a.r[i] = reinterpret_cast<const float4*>(q)[i];
-    a.r16 = (2 * x0 + 16 < p.Wo) ? q[16] : 0.f;
+    for (int i = 0; i < 4; ++i) a.r[i] = q.ld4(4 * i);
+    a.r16 = (2 * x0 + 16 < p.Wo) ? q.ld1(16) : 0.f;
   };
   uint4 af[3][NP];
   auto convert_a = [&](const ARaw& a) __attribute__((always_inline)) {
@@ -683,8 +695,7 @@ __global__ __launch_bounds__(192 * MO, 3) void c3_wgrad_k(const C3Wgrad p) {
       const int sg = min(kstep * 4 + (q >> 1), SG - 1);
       const int ns_ = sg / (p.H * W8);
       const int rem = sg - ns_ * (p.H * W8);  // = y * W8 + x8  ->  pixel offset 8 * rem
-      br[i] = *reinterpret_cast<const float4*>(p.X + (long long)ns_ * p.ns + (long long)c * p.cs + (long long)rem * 8 +
-                                               4 * (q & 1));
+      br[i] = SP<ST>(p.X).ld4((long long)ns_ * p.ns + (long long)c * p.cs + (long long)rem * 8 + 4 * (q & 1));
     }
   };
   auto commit_b = [&](int kstep, int buf) __attribute__((always_inline)) {
@@ -771,7 +782,8 @@ __global__ __launch_bounds__(192 * MO, 3) void c3_wgrad_k(const C3Wgrad p) {
 bool c3_wgrad_supported(const C3Wgrad& p) {
   if (p.H < 1 || p.W < 8 || (p.W & 7) || p.N < 1 || p.Cin < 1 || p.Cout < 1) return false;
   if (p.Wo != 2 * p.W || (p.Ho != 2 * p.H && p.Ho != 2 * p.H + 1)) return false;
-  if ((p.ns & 3) || (p.cs & 3) || (reinterpret_cast<uintptr_t>(p.X) & 15) || (reinterpret_cast<uintptr_t>(p.dU) & 15))
+  if ((p.ns & 3) || (p.cs & 3) || (reinterpret_cast<uintptr_t>(p.X) & (p.st == ST_BF16 ? 7 : 15)) ||
+      (reinterpret_cast<uintptr_t>(p.dU) & (p.yt == ST_BF16 ? 7 : 15)))
     return false;
   if ((long long)p.N * p.H * p.W + 64 >= (1ll << 31)) return false;
   return true;
@@ -791,13 +803,13 @@ void c3_wgrad_plan(C3Wgrad* p) {
   p->nranges = (int)((ksteps + per - 1) / per);
 }
 
-template <int NP, int DT>
+template <int NP, int DT, int ST = ST_F32, int YT = ST_F32>
 static int c3_wgrad_launch_t(const C3Wgrad& p, hipStream_t s) {
   const size_t lds = (size_t)2 * p.nc * NP * 1024;
   const dim3 grid((unsigned)(p.nranges * p.ogroups * p.cgroups));
   if (p.nc * 16 * 8 > 768) return -4;  // staging budget of the block's threads
-  if (p.mo == 2) hipLaunchKernelGGL((c3_wgrad_k<NP, DT, 2>), grid, dim3(384), lds, s, p);
-  else hipLaunchKernelGGL((c3_wgrad_k<NP, DT, 1>), grid, dim3(192), lds, s, p);
+  if (p.mo == 2) hipLaunchKernelGGL((c3_wgrad_k<NP, DT, 2, ST, YT>), grid, dim3(384), lds, s, p);
+  else hipLaunchKernelGGL((c3_wgrad_k<NP, DT, 1, ST, YT>), grid, dim3(192), lds, s, p);
   return (int)hipGetLastError();
 }
 
@@ -806,6 +818,12 @@ int c3_wgrad_launch(const C3Wgrad& p, int np, int dt, hipStream_t s) {
       p.nranges < 1 || p.per < 1)
     return -4;
   if (p.mo * p.ogroups * 16 < p.Cout || p.nc * p.cgroups * 16 < p.Cin) return -4;
+  if (p.st == ST_BF16 || p.yt == ST_BF16) {  // bf16 storage = plain bf16 operands
+    if (np != 1 || dt != D3_BF16) return -4;
+    if (p.st == ST_BF16 && p.yt == ST_BF16) return c3_wgrad_launch_t<1, D3_BF16, ST_BF16, ST_BF16>(p, s);
+    if (p.st == ST_BF16) return c3_wgrad_launch_t<1, D3_BF16, ST_BF16, ST_F32>(p, s);
+    return c3_wgrad_launch_t<1, D3_BF16, ST_F32, ST_BF16>(p, s);
+  }
   if (dt == D3_BF16) {
     if (np == 1) return c3_wgrad_launch_t<1, D3_BF16>(p, s);
     if (np == 2) return c3_wgrad_launch_t<2, D3_BF16>(p, s);

@@ -56,6 +56,7 @@ struct D3Fwd {
   int ksplit;           // >1: raw partial sums to out + split*split_stride (no bias / scale / statistics)
   long long split_stride;
   int dbg;              // diagnostic builds (-DRLN_DIAG) only: 1 no global loads, 2 no commit, 4 no MFMA phase, 8 no zero-init
+  int st;               // storage element type of S and out (storage.h): ST_F32, or ST_BF16 (then np = 1, bf16 operands)
 };
 // true when the launch geometry is supported (W % 4 == 0, 16-byte aligned planes, W >= 40, Cout <= 16)
 bool d3_fwd_supported(const D3Fwd& p);
@@ -82,6 +83,7 @@ struct D3Wgrad {
   int nchunks, nranges;
   float* partial;  // [nranges][Cout*Cin*9], layout [o][c][tap]
   int dbg;         // diagnostic builds (-DRLN_DIAG) only: 1 no global loads, 2 no commit, 4 no MFMA phase
+  int st;          // storage element type of S and dY (storage.h)
 };
 bool d3_wgrad_supported(const D3Wgrad& p);
 void d3_wgrad_plan(int H, int W, int N, int Cin, D3Wgrad* p);  // fills th, tw, tiles, rg, nchunks, nranges
@@ -114,6 +116,7 @@ struct D3Pull {
   int H, W, N;
   int th, tw, tiles_x, tiles_y;
   float* stat_partial;            // [2*blocks][nl][Cpad][2], Cpad = 16*ceil(C/16) (two rows per block)
+  int st;                         // storage element type of S and of the dY buffers (storage.h); G is fp32
 };
 bool d3_pull_supported(const D3Pull& p, int np);  // geometry + LDS budget (set nl, C, th, tw first)
 void d3_pull_pick_tile(int H, int W, int* th, int* tw);

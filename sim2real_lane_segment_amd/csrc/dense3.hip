@@ -1,6 +1,7 @@
 // Dense-block 3x3 kernels on the 16-bit MFMA pipe with split fp32 operands (see dense3.h).
 #include "dense3.h"
 #include "split16.h"
+#include "storage.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -99,7 +100,7 @@ int d3_pack_weights(const float* params, const D3PackDesc* desc_dev, int n_desc,
 // padding applies AFTER the activation).  Interior rows are fetched as 16-byte segments (NR rounds of 8 channels x 4
 // pixels per producer thread), the two halo columns as scalars.
 // =============================================================================================
-template <int MPW, int NR, int NP, int DT>
+template <int MPW, int NR, int NP, int DT, int ST>
 __global__ __launch_bounds__(768, 3) void d3_fwd_k(const D3Fwd p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(768, 3) void d3_fwd_k(const D3Fwd p) {
   }
   const int tile_y = bx / p.tiles_x, tile_x = bx - tile_y * p.tiles_x;
   const int gy0 = tile_y * p.th, gx0 = tile_x * p.tw;
-  const float* Sn = p.S + (long long)n * p.ns;
+  const SP<ST> Sn = SP<ST>(p.S) + (long long)n * p.ns;
 
   // chunk range of this block (split-K over blockIdx.y)
   const int per = (nchunk_all + (int)gridDim.y - 1) / (int)gridDim.y;
@@ -204,8 +205,8 @@ __global__ __launch_bounds__(768, 3) void d3_fwd_k(const D3Fwd p) {
     constexpr int NB = (NBE + 511) / 512;        // per producer thread
 
     struct Stage {
-      float4 s[8];
-      float h[2];
+      typename SRaw<ST>::r4 s[8];  // narrow registers until the commit widens them
+      typename SRaw<ST>::r1 h[2];
       uint4 b[NB];
     };
     Stage RA, RB;
@@ -215,14 +216,14 @@ __global__ __launch_bounds__(768, 3) void d3_fwd_k(const D3Fwd p) {
 #ifdef RLN_DIAG
       if (p.dbg & 1) return;
 #endif
-      const float* base = Sn + (long long)chunk_base(chunk) * p.cs;  // wave-uniform
+      const SP<ST> base = Sn + (long long)chunk_base(chunk) * p.cs;  // wave-uniform
       const uint4* wp = p.wpk + (long long)chunk * NBE;
 #pragma unroll
       for (int i = 0; i < NB; ++i) R.b[i] = wp[min(ptid + 512 * i, NBE - 1)];
 #pragma unroll
-      for (int cc = 0; cc < 8; ++cc) R.s[cc] = *reinterpret_cast<const float4*>(base + s_off[cc]);
-      R.h[0] = base[h_goff];
-      R.h[1] = base[h_goff + p.cs];
+      for (int cc = 0; cc < 8; ++cc) R.s[cc] = base.raw4(s_off[cc]);
+      R.h[0] = base.raw1(h_goff);
+      R.h[1] = base.raw1(h_goff + p.cs);
     };
     auto commit = [&](int chunk, unsigned char* buf, const Stage& R) __attribute__((always_inline)) {
 #ifdef RLN_DIAG
@@ -236,8 +237,8 @@ __global__ __launch_bounds__(768, 3) void d3_fwd_k(const D3Fwd p) {
       if (h_ok) {
         const int c0 = cb + 2 * h_cp;
         unsigned parts[NP];
-        split2<DT, NP>(fmaxf(fmaf(abtab[c0], R.h[0], abtab[Cpad + c0]), 0.f),
-                       fmaxf(fmaf(abtab[c0 + 1], R.h[1], abtab[Cpad + c0 + 1]), 0.f), parts);
+        split2<DT, NP>(fmaxf(fmaf(abtab[c0], SRaw<ST>::w1(R.h[0]), abtab[Cpad + c0]), 0.f),
+                       fmaxf(fmaf(abtab[c0 + 1], SRaw<ST>::w1(R.h[1]), abtab[Cpad + c0 + 1]), 0.f), parts);
 #pragma unroll
         for (int pt = 0; pt < NP; ++pt) *reinterpret_cast<unsigned*>(buf + pt * PLANE + h_lds) = parts[pt];
       }
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(768, 3) void d3_fwd_k(const D3Fwd p) {
           unsigned parts[4][NP];
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const float4 u0 = R.s[2 * k], u1 = R.s[2 * k + 1];
+            const float4 u0 = SRaw<ST>::w4(R.s[2 * k]), u1 = SRaw<ST>::w4(R.s[2 * k + 1]);
             const float x0 = px == 0 ? u0.x : px == 1 ? u0.y : px == 2 ? u0.z : u0.w;
             const float x1 = px == 0 ? u1.x : px == 1 ? u1.y : px == 2 ? u1.z : u1.w;
             split2<DT, NP>(fmaxf(fmaf(av[2 * k], x0, bv[2 * k]), 0.f),
@@ -369,8 +370,8 @@ __global__ __launch_bounds__(768, 3) void d3_fwd_k(const D3Fwd p) {
     const bool jv = j < p.Cout;
     const float bias = (jv && !raw && p.bias) ? p.bias[j] : 0.f;
     const float sc = (jv && !raw && p.nscale) ? p.nscale[(long long)n * p.Cout + j] : 1.f;
-    float* outn = p.out + (raw ? (long long)blockIdx.y * p.split_stride : 0) + (long long)n * p.out_ns +
-                  (long long)(jv ? j : 0) * p.out_cs;
+    const SP<ST> outn = SP<ST>(p.out) + ((raw ? (long long)blockIdx.y * p.split_stride : 0) + (long long)n * p.out_ns +
+                                         (long long)(jv ? j : 0) * p.out_cs);
 #pragma unroll
     for (int m = 0; m < MPW; ++m) {
       const int q = (wave * MPW + m) * 16 + lg * 4;
@@ -380,13 +381,13 @@ __global__ __launch_bounds__(768, 3) void d3_fwd_k(const D3Fwd p) {
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        v[r] = (acc[m][r] + bias) * sc;
+        v[r] = st_round<ST>((acc[m][r] + bias) * sc);  // the statistics describe the tensor as it is stored
         if (ok) {
           s1 += v[r];
           s2 += v[r] * v[r];
         }
       }
-      if (ok) *reinterpret_cast<float4*>(outn + (long long)gy * p.W + gx) = make_float4(v[0], v[1], v[2], v[3]);
+      if (ok) outn.st4((long long)gy * p.W + gx, v[0], v[1], v[2], v[3]);
     }
   }
   if (p.stat_partial != nullptr && !raw) {
@@ -413,7 +414,9 @@ bool d3_fwd_supported(const D3Fwd& p) {
   if (p.Cout > 16 || p.Cout < 1 || p.Cin < 1) return false;
   if ((p.W & 3) || p.W < 40 || p.H < 4) return false;
   if ((p.cs & 3) || (p.ns & 3) || (p.out_cs & 3) || (p.out_ns & 3)) return false;
-  if ((reinterpret_cast<uintptr_t>(p.S) & 15) || (reinterpret_cast<uintptr_t>(p.out) & 15)) return false;
+  const uintptr_t amask = p.st == ST_BF16 ? 7 : 15;  // a quad of elements per load / store
+  if ((reinterpret_cast<uintptr_t>(p.S) & amask) || (reinterpret_cast<uintptr_t>(p.out) & amask)) return false;
+  if (p.st == ST_BF16 && p.ksplit > 1) return false;  // split-K partial sums are fp32 scratch
   return true;
 }
 
@@ -439,12 +442,12 @@ void d3_fwd_pick_tile(int H, int W, int np, int* th, int* tw, int* rg) {
   *rg = units(4) <= 512 ? 4 : 2;  // 512 producer threads, one unit each
 }
 
-template <int MPW, int NR, int NP, int DT>
+template <int MPW, int NR, int NP, int DT, int ST = ST_F32>
 static int d3_fwd_launch_t(const D3Fwd& p, int N, hipStream_t s) {
   const int P = p.tw + 3, rows = p.th + 2;
   const int Cpad = ((p.Cin + 15) / 16) * 16;
   const size_t lds = 2 * ((size_t)NP * rows * P * 32 + (size_t)5 * NP * 1024) + (size_t)2 * Cpad * 4 + 4 * 16 * 2 * 4;
-  auto kern = d3_fwd_k<MPW, NR, NP, DT>;
+  auto kern = d3_fwd_k<MPW, NR, NP, DT, ST>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -468,6 +471,10 @@ int d3_fwd_launch(const D3Fwd& p, int N, int np, int dt, hipStream_t s) {
   if ((p.th + 2) * 16 > 512 || lane_units > 512 || (p.tw & 3) || (p.rg != 2 && p.rg != 4)) return -4;
 #define D3_FWD(MPW_, NR_)                                                                         \
   do {                                                                                            \
+    if (p.st == ST_BF16) {                                                                        \
+      if (np != 1 || dt != D3_BF16) return -4; /* bf16 storage = plain bf16 operands */           \
+      return d3_fwd_launch_t<MPW_, NR_, 1, D3_BF16, ST_BF16>(p, N, s);                            \
+    }                                                                                             \
     if (dt == D3_BF16) {                                                                          \
       if (np == 1) return d3_fwd_launch_t<MPW_, NR_, 1, D3_BF16>(p, N, s);                        \
       if (np == 2) return d3_fwd_launch_t<MPW_, NR_, 2, D3_BF16>(p, N, s);                        \
@@ -499,7 +506,7 @@ __device__ __forceinline__ uint2 lds_tr16(const unsigned char* p) {
   return c.u;
 }
 
-template <int NP, int DT>
+template <int NP, int DT, int ST>
 __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -581,13 +588,14 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
       const int ch = kind == 0 ? cb + u_o * 8 + cc : (kind == 1 ? min(u_o * 8 + cc, p.Cout - 1) : cb + 4 * u_o + (cc & 3));
       choff[cc] = ch * p.cs;
     }
-    const float* kbase = kind == 1 ? p.dY : p.S;
+    typedef typename SRaw<ST>::r4 Raw4;  // S and dY share the level's storage type
+    const SP<ST> kbase(kind == 1 ? p.dY : p.S);
     const long long kns = kind == 1 ? (long long)p.Cout * p.cs : p.ns;
-    float4 regA[8], regB[8];
+    Raw4 regA[8], regB[8];
     bool okA = false, okB = false;
     // tiles are requested strictly in order t0, t0+1, ...: a cursor replaces two integer divisions per request
     int cur_n = t0 / tiles, cur_ty = (t0 - cur_n * tiles) / p.tiles_x, cur_tx = (t0 - cur_n * tiles) - cur_ty * p.tiles_x;
-    auto issue = [&](int /*t: the cursor's tile*/, float4 (&reg)[8], bool& okf) __attribute__((always_inline)) {
+    auto issue = [&](int /*t: the cursor's tile*/, Raw4 (&reg)[8], bool& okf) __attribute__((always_inline)) {
       const int n = cur_n;
       const int gy0 = cur_ty * p.th, gx0 = cur_tx * p.tw;
       if (++cur_tx == p.tiles_x) {
@@ -613,15 +621,18 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
         ok = u_ex && iy >= 0 && iy < p.H && hx >= 0 && hx < p.W;
         ix = h_side ? hx : hx - 3;
       }
-      const float* src = kbase + (long long)n * kns + (ok ? iy * p.W + ix : 0);
+      const SP<ST> src = kbase + ((long long)n * kns + (ok ? iy * p.W + ix : 0));
 #ifdef RLN_DIAG
       if (!(p.dbg & 1) && !((p.dbg & 8) && kind == 1) && !((p.dbg & 16) && kind != 1))
 #endif
 #pragma unroll
-      for (int cc = 0; cc < 8; ++cc) reg[cc] = *reinterpret_cast<const float4*>(src + choff[cc]);
+      for (int cc = 0; cc < 8; ++cc) reg[cc] = src.raw4(choff[cc]);
       okf = ok;
     };
-    auto commit = [&](int buf, const float4 (&reg)[8], bool okf) __attribute__((always_inline)) {
+    auto commit = [&](int buf, const Raw4 (&rawreg)[8], bool okf) __attribute__((always_inline)) {
+      float4 reg[8];
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) reg[cc] = SRaw<ST>::w4(rawreg[cc]);
       unsigned char* zb = zbuf + buf * ZB;
       unsigned char* yb = ybuf + buf * YB;
       if (!u_ex) return;
@@ -799,7 +810,8 @@ bool d3_wgrad_supported(const D3Wgrad& p) {
   if (p.Cout < 1 || p.Cout > 16 || p.Cin < 1) return false;
   if ((p.W % 40) != 0 || p.H < 4) return false;
   if ((p.cs & 3) || (p.ns & 3)) return false;
-  if ((reinterpret_cast<uintptr_t>(p.S) & 15) || (reinterpret_cast<uintptr_t>(p.dY) & 15)) return false;
+  const uintptr_t amask = p.st == ST_BF16 ? 7 : 15;
+  if ((reinterpret_cast<uintptr_t>(p.S) & amask) || (reinterpret_cast<uintptr_t>(p.dY) & amask)) return false;
   return true;
 }
 
@@ -822,12 +834,12 @@ void d3_wgrad_plan(int H, int W, int N, int Cin, D3Wgrad* p) {
   p->nranges = (int)((total + per - 1) / per);  // no empty ranges
 }
 
-template <int NP, int DT>
+template <int NP, int DT, int ST = ST_F32>
 static int d3_wgrad_launch_t(const D3Wgrad& p, hipStream_t s) {
   const int P = p.tw + 3, rows = p.th + 2;
   const size_t lds = (size_t)2 * NP * rows * P * 32 + (size_t)2 * NP * p.th * p.tw * 32 + 128;
   if (lds > 160 * 1024 || lds < 4 * 9 * 64 * 16) return -4;
-  auto kern = d3_wgrad_k<NP, DT>;
+  auto kern = d3_wgrad_k<NP, DT, ST>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -842,6 +854,10 @@ static int d3_wgrad_launch_t(const D3Wgrad& p, hipStream_t s) {
 int d3_wgrad_launch(const D3Wgrad& p, int np, int dt, hipStream_t s) {
   if (!d3_wgrad_supported(p) || p.th * p.tw != 320 || (p.tw != 80 && p.tw != 40) || p.rg != 2) return -4;
   if ((p.th + 2) * 8 > 96 || p.th * (p.tw / 4) * 2 > 160) return -4;  // halo / dY unit budgets of the producer threads
+  if (p.st == ST_BF16) {
+    if (np != 1 || dt != D3_BF16) return -4;
+    return d3_wgrad_launch_t<1, D3_BF16, ST_BF16>(p, s);
+  }
   if (dt == D3_BF16) {
     if (np == 1) return d3_wgrad_launch_t<1, D3_BF16>(p, s);
     if (np == 2) return d3_wgrad_launch_t<2, D3_BF16>(p, s);
@@ -862,7 +878,7 @@ int d3_wgrad_launch(const D3Wgrad& p, int np, int dt, hipStream_t s) {
 // per-(layer, channel) slots in LDS.  G is written once per group.  Two waves per SIMD: one wave's epilogue VALU work
 // overlaps the other's MFMAs.
 // =============================================================================================
-template <int NP, int DT>
+template <int NP, int DT, int ST>
 __global__ __launch_bounds__(512, 2) void d3_pull_k(const D3Pull p) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int MT = 5;  // M-tiles per work item: an item = (output-channel group, half of the 160-pixel tile)
@@ -915,7 +931,7 @@ __global__ __launch_bounds__(512, 2) void d3_pull_k(const D3Pull p) {
     // ---- stage the dY images (zero outside the picture and beyond Cout): all loads first, then convert ----
     {
       constexpr int NRD = 2;  // staging rounds (nl * lul <= 1024: checked by the launcher)
-      float4 v[NRD][8];
+      typename SRaw<ST>::r4 v[NRD][8];  // dY shares the level's storage type with S
       float hv[2];
       int sdst[NRD];
       unsigned sflag[NRD];  // bit 0: unit exists, bit 1: inside the picture, bits 8..: octet
@@ -930,11 +946,11 @@ __global__ __launch_bounds__(512, 2) void d3_pull_k(const D3Pull p) {
         const bool ex = lu < p.nl * lul && r < rows;
         const int iy = gy0 - 1 + r, ix = gx0 + 4 * Q;
         const bool ok = ex && iy >= 0 && iy < p.H && ix < p.W;
-        const float* src = p.dY[j] + ((long long)n * p.Cout) * p.cs + (ok ? iy * p.W + ix : 0);
+        const SP<ST> src = SP<ST>(p.dY[j]) + (((long long)n * p.Cout) * p.cs + (ok ? iy * p.W + ix : 0));
 #pragma unroll
         for (int cc = 0; cc < 8; ++cc) {
           const int ch = min(o * 8 + cc, p.Cout - 1);
-          v[i][cc] = *reinterpret_cast<const float4*>(src + (long long)ch * p.cs);
+          v[i][cc] = src.raw4((long long)ch * p.cs);
         }
         sdst[i] = j * LIMG + ((ex ? r : 0) * P + 1 + 4 * Q) * 32 + o * 16;
         sflag[i] = (ex ? 1u : 0u) | (ok ? 2u : 0u) | ((unsigned)o << 8);
@@ -949,9 +965,9 @@ __global__ __launch_bounds__(512, 2) void d3_pull_k(const D3Pull p) {
         const bool ex = hu < p.nl * hul;
         const int iy = gy0 - 1 + r, ix = side ? gx0 + p.tw : gx0 - 1;
         const bool ok = ex && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        const float* src = p.dY[j] + ((long long)n * p.Cout) * p.cs + (ok ? iy * p.W + ix : 0);
-        hv[0] = src[(long long)min(2 * cp, p.Cout - 1) * p.cs];
-        hv[1] = src[(long long)min(2 * cp + 1, p.Cout - 1) * p.cs];
+        const SP<ST> src = SP<ST>(p.dY[j]) + (((long long)n * p.Cout) * p.cs + (ok ? iy * p.W + ix : 0));
+        hv[0] = src.ld1((long long)min(2 * cp, p.Cout - 1) * p.cs);
+        hv[1] = src.ld1((long long)min(2 * cp + 1, p.Cout - 1) * p.cs);
         if (!ok || 2 * cp >= p.Cout) hv[0] = 0.f;
         if (!ok || 2 * cp + 1 >= p.Cout) hv[1] = 0.f;
         hdst = j * LIMG + ((ex ? r : 0) * P + (side ? p.tw + 1 : 0)) * 32 + cp * 4;
@@ -967,7 +983,7 @@ __global__ __launch_bounds__(512, 2) void d3_pull_k(const D3Pull p) {
             unsigned parts[4][NP];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-              const float4 u0 = v[i][2 * k], u1 = v[i][2 * k + 1];
+              const float4 u0 = SRaw<ST>::w4(v[i][2 * k]), u1 = SRaw<ST>::w4(v[i][2 * k + 1]);
               float x0 = px == 0 ? u0.x : px == 1 ? u0.y : px == 2 ? u0.z : u0.w;
               float x1 = px == 0 ? u1.x : px == 1 ? u1.y : px == 2 ? u1.z : u1.w;
               if (!ok || o * 8 + 2 * k >= p.Cout) x0 = 0.f;
@@ -991,7 +1007,7 @@ __global__ __launch_bounds__(512, 2) void d3_pull_k(const D3Pull p) {
     __syncthreads();
 
     // ---- per-wave loop over work items (no barriers) ----
-    const float* Sn = p.S + (long long)n * p.s_ns;
+    const SP<ST> Sn = SP<ST>(p.S) + (long long)n * p.s_ns;
     float* Gn = p.G + (long long)n * p.s_ns;
     uint4 bf[5][NP];
     bool bf_valid = false;
@@ -1019,11 +1035,11 @@ __global__ __launch_bounds__(512, 2) void d3_pull_k(const D3Pull p) {
       const bool cv = c < p.C;
       const int cc = cv ? c : p.C - 1;
       const bool accum = c >= p.acc_lo && c < p.acc_hi;
-      const float* Sc = Sn + (long long)cc * p.cs;
+      const SP<ST> Sc = Sn + (long long)cc * p.cs;
       float* Gc = Gn + (long long)cc * p.cs;
       float4 sv[MT];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) sv[m] = *reinterpret_cast<const float4*>(Sc + goff[m]);
+      for (int m = 0; m < MT; ++m) sv[m] = Sc.ld4(goff[m]);
       const float mean = mtab[(g * 16 + lp) * 2], invstd = mtab[(g * 16 + lp) * 2 + 1];
       f32x4 gsum[MT];
 #pragma unroll
@@ -1175,9 +1191,10 @@ bool d3_pull_supported(const D3Pull& p, int np) {
   if (p.th * p.tw != 160 || d3_pull_lds(p, np) > 160 * 1024) return false;
   if ((p.W & 3) || (p.cs & 3) || (p.s_ns & 3)) return false;
   if (!(p.W % 80 == 0 || p.W == 40)) return false;
-  if ((reinterpret_cast<uintptr_t>(p.S) & 15) || (reinterpret_cast<uintptr_t>(p.G) & 15)) return false;
+  const uintptr_t amask = p.st == ST_BF16 ? 7 : 15;
+  if ((reinterpret_cast<uintptr_t>(p.S) & amask) || (reinterpret_cast<uintptr_t>(p.G) & 15)) return false;
   for (int j = 0; j < p.nl; ++j)
-    if (reinterpret_cast<uintptr_t>(p.dY[j]) & 15) return false;
+    if (reinterpret_cast<uintptr_t>(p.dY[j]) & amask) return false;
   return true;
 }
 
@@ -1197,11 +1214,11 @@ int d3_pull_blocks(const D3Pull& p) {
   return (int)std::min<long long>(total, 256);
 }
 
-template <int NP, int DT>
+template <int NP, int DT, int ST = ST_F32>
 static int d3_pull_launch_t(const D3Pull& p, hipStream_t s) {
   const size_t lds = d3_pull_lds(p, NP);
   if (lds > 160 * 1024) return -4;
-  auto kern = d3_pull_k<NP, DT>;
+  auto kern = d3_pull_k<NP, DT, ST>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1215,6 +1232,10 @@ static int d3_pull_launch_t(const D3Pull& p, hipStream_t s) {
 
 int d3_pull_launch(const D3Pull& p, int np, int dt, hipStream_t s) {
   if (!d3_pull_supported(p, np)) return -4;
+  if (p.st == ST_BF16) {
+    if (np != 1 || dt != D3_BF16) return -4;
+    return d3_pull_launch_t<1, D3_BF16, ST_BF16>(p, s);
+  }
   if (dt == D3_BF16) {
     if (np == 1) return d3_pull_launch_t<1, D3_BF16>(p, s);
     if (np == 2) return d3_pull_launch_t<2, D3_BF16>(p, s);

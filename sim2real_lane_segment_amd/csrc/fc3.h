@@ -18,6 +18,7 @@ struct F3Fwd {
   int out_cs, Cout;
   float* stat_partial;  // [blocks][Cout][2] or null
   int blocks;
+  int ot;  // storage element type of out (storage.h); X is the fp32 input batch
 };
 bool f3_fwd_supported(const F3Fwd& p);
 void f3_fwd_plan(F3Fwd* p);
@@ -30,6 +31,7 @@ struct F3Wgrad {
   int Cout;
   float* partial;  // [blocks][Cout][Cin*9]
   int blocks;
+  int yt;  // storage element type of dY (storage.h)
 };
 bool f3_wgrad_supported(const F3Wgrad& p);
 void f3_wgrad_plan(F3Wgrad* p);

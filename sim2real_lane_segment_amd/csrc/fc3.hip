@@ -4,6 +4,7 @@
 #include <algorithm>
 
 #include "split16.h"
+#include "storage.h"
 
 namespace rln {
 
@@ -17,7 +18,7 @@ constexpr int F3_MT = 4;  // M tiles (16 output channels each) at most
 // so its four accumulators of a channel are one 16-byte store) and the K entries 8kb..8kb+7, i.e. 8 (channel, tap)
 // pairs whose shifted pixels it loads directly (zero outside the image).
 // =============================================================================================
-template <int NP, int DT>
+template <int NP, int DT, int OT>
 __global__ __launch_bounds__(256, 2) void f3_fwd_k(const F3Fwd p) {
   __shared__ __align__(16) uint4 wl[F3_MT * 3 * 64];  // [mtile][part][lane] (NP <= 3)
   __shared__ float btab[F3_MT * 16];
@@ -105,8 +106,10 @@ __global__ __launch_bounds__(256, 2) void f3_fwd_k(const F3Fwd p) {
         for (int r = 0; r < 4; ++r) {
           const int o = m * 16 + kb4 + r;
           const bool st = pv && o < p.Cout;
-          const float4 ov = make_float4(acc[0][r] + bia[r], acc[1][r] + bia[r], acc[2][r] + bia[r], acc[3][r] + bia[r]);
-          if (st) *reinterpret_cast<float4*>(p.out + (long long)ns_ * p.out_ns + (long long)o * p.out_cs + rem) = ov;
+          // (rounded to the storage type first: the statistics describe the tensor as it is stored)
+          const float4 ov = make_float4(st_round<OT>(acc[0][r] + bia[r]), st_round<OT>(acc[1][r] + bia[r]),
+                                        st_round<OT>(acc[2][r] + bia[r]), st_round<OT>(acc[3][r] + bia[r]));
+          if (st) SP<OT>(p.out).st4((long long)ns_ * p.out_ns + (long long)o * p.out_cs + rem, ov.x, ov.y, ov.z, ov.w);
           float s1 = st ? (ov.x + ov.y) + (ov.z + ov.w) : 0.f;
           float s2 = st ? (ov.x * ov.x + ov.y * ov.y) + (ov.z * ov.z + ov.w * ov.w) : 0.f;
           s1 = row16_sum(s1);
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void f3_fwd_k(const F3Fwd p) {
 bool f3_fwd_supported(const F3Fwd& p) {
   if (p.Cin < 1 || p.Cin * 9 > 32 || p.Cout < 1 || p.Cout > F3_MT * 16 || p.N < 1) return false;
   if (p.H < 1 || p.W < 4 || (p.W & 3) || (p.out_cs & 3) || (p.out_ns & 3)) return false;
-  if (reinterpret_cast<uintptr_t>(p.out) & 15) return false;
+  if (reinterpret_cast<uintptr_t>(p.out) & (p.ot == ST_BF16 ? 7 : 15)) return false;
   return true;
 }
 
@@ -147,8 +150,11 @@ void f3_fwd_plan(F3Fwd* p) {
 int f3_fwd_launch(const F3Fwd& p, int np, int dt, hipStream_t s) {
   if (!f3_fwd_supported(p) || p.blocks < 1) return -4;
   const dim3 grid((unsigned)p.blocks);
-#define F3_FWD(NP_, DT_) hipLaunchKernelGGL((f3_fwd_k<NP_, DT_>), grid, dim3(256), 0, s, p)
-  if (dt == D3_BF16) {
+#define F3_FWD(NP_, DT_) hipLaunchKernelGGL((f3_fwd_k<NP_, DT_, ST_F32>), grid, dim3(256), 0, s, p)
+  if (p.ot == ST_BF16) {  // bf16 storage = plain bf16 operands
+    if (np != 1 || dt != D3_BF16) return -4;
+    hipLaunchKernelGGL((f3_fwd_k<1, D3_BF16, ST_BF16>), grid, dim3(256), 0, s, p);
+  } else if (dt == D3_BF16) {
     if (np == 1) F3_FWD(1, D3_BF16);
     else if (np == 2) F3_FWD(2, D3_BF16);
     else if (np == 3) F3_FWD(3, D3_BF16);
@@ -172,7 +178,7 @@ int f3_fwd_launch(const F3Fwd& p, int np, int dt, hipStream_t s) {
 // loads, zero outside the image).  Waves take K steps round-robin; the block's 4 waves are summed through LDS and one
 // partial row per block is written (reduced afterwards in fixed order).
 // =============================================================================================
-template <int NP, int DT>
+template <int NP, int DT, int YT>
 __global__ __launch_bounds__(256, 2) void f3_wgrad_k(const F3Wgrad p) {
   __shared__ float red[4 * F3_MT * 2 * 256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -224,14 +230,14 @@ __global__ __launch_bounds__(256, 2) void f3_wgrad_k(const F3Wgrad p) {
       for (int pt = 0; pt < NP; ++pt) bf[i][pt] = make_uint4(w[0][pt], w[1][pt], w[2][pt], w[3][pt]);
     }
     // A fragments and products
-    const float* yb = p.dY + (long long)ns_ * p.Cout * HW + rem;
+    const SP<YT> yb = SP<YT>(p.dY) + ((long long)ns_ * p.Cout * HW + rem);
 #pragma unroll
     for (int m = 0; m < F3_MT; ++m) {
       if (m < MT) {
         const int o = min(m * 16 + n16, p.Cout - 1);
         const bool ov = pv && (m * 16 + n16 < p.Cout);
-        const float4 u0 = *reinterpret_cast<const float4*>(yb + (long long)o * HW);
-        const float4 u1 = *reinterpret_cast<const float4*>(yb + (long long)o * HW + 4);
+        const float4 u0 = yb.ld4((long long)o * HW);
+        const float4 u1 = yb.ld4((long long)o * HW + 4);
         unsigned w[4][NP];
         split2<DT, NP>(ov ? u0.x : 0.f, ov ? u0.y : 0.f, w[0]);
         split2<DT, NP>(ov ? u0.z : 0.f, ov ? u0.w : 0.f, w[1]);
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void f3_wgrad_k(const F3Wgrad p) {
 bool f3_wgrad_supported(const F3Wgrad& p) {
   if (p.Cin < 1 || p.Cin * 9 > 32 || p.Cout < 1 || p.Cout > F3_MT * 16 || p.N < 1) return false;
   if (p.H < 1 || p.W < 8 || (p.W & 7)) return false;
-  if (reinterpret_cast<uintptr_t>(p.dY) & 15) return false;
+  if (reinterpret_cast<uintptr_t>(p.dY) & (p.yt == ST_BF16 ? 7 : 15)) return false;
   return true;
 }
 
@@ -278,8 +284,11 @@ void f3_wgrad_plan(F3Wgrad* p) {
 int f3_wgrad_launch(const F3Wgrad& p, int np, int dt, hipStream_t s) {
   if (!f3_wgrad_supported(p) || p.blocks < 1) return -4;
   const dim3 grid((unsigned)p.blocks);
-#define F3_WG(NP_, DT_) hipLaunchKernelGGL((f3_wgrad_k<NP_, DT_>), grid, dim3(256), 0, s, p)
-  if (dt == D3_BF16) {
+#define F3_WG(NP_, DT_) hipLaunchKernelGGL((f3_wgrad_k<NP_, DT_, ST_F32>), grid, dim3(256), 0, s, p)
+  if (p.yt == ST_BF16) {  // bf16 storage = plain bf16 operands
+    if (np != 1 || dt != D3_BF16) return -4;
+    hipLaunchKernelGGL((f3_wgrad_k<1, D3_BF16, ST_BF16>), grid, dim3(256), 0, s, p);
+  } else if (dt == D3_BF16) {
     if (np == 1) F3_WG(1, D3_BF16);
     else if (np == 2) F3_WG(2, D3_BF16);
     else if (np == 3) F3_WG(3, D3_BF16);

@@ -53,6 +53,7 @@ struct IgemmParams {
   long long split_stride;
   int dbg;             // timing ablations only (RLN_DBG): 1 skip global loads, 2 skip LDS commit, 4 skip MFMA, 16 stamps, 32 no XCD remap
   unsigned long long* dbg_out;  // [8] phase cycle sums (diagnostic build path only)
+  int st;              // dgrad_loop_launch only: storage element type of `in` (dY) and S (storage.h); 0 = fp32 elsewhere
 };
 unsigned long long* igemm_debug_buffer();  // device buffer of 8 counters (allocated on first use)
 

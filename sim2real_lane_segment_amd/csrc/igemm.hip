@@ -11,6 +11,7 @@
 // (16 consecutive pixels x 4 channels) touches 64 distinct banks; weights [kgroup][tap][ntile][64]
 // so that the B-operand read is lane-linear.
 #include "igemm.h"
+#include "storage.h"
 
 #include <algorithm>
 #include <cstdint>
@@ -857,7 +858,7 @@ int igemm_launch(IgemmKind kind, int tile, const IgemmParams& p, int N, hipStrea
 // VEC: rows are 16-byte aligned and W % 4 == 0 (host-checked), so every 4-pixel group is all-in or all-out and the
 // S / G traffic moves as one 16-byte access per lane.  A compile-time switch: as a run-time branch the compiler
 // folds both forms into the scalar one (32 dword loads per lane and step instead of 8 dwordx4).
-template <int TH, int TW, bool VEC>
+template <int TH, int TW, bool VEC, int ST>  // ST: storage element type of dY (p.in) and S; G (p.out) is fp32
 __global__ __launch_bounds__(256, 3) void dgrad_loop_k(const IgemmParams p) {
   using C = IgCfg<3, 1, PRO_RAW, EPI_DGRAD, TH, TW>;
   constexpr int MPW = C::MPW;
@@ -874,7 +875,7 @@ __global__ __launch_bounds__(256, 3) void dgrad_loop_k(const IgemmParams p) {
 
   // ---- stage the dY tile once (clamped unconditional loads + select) ----
   {
-    const float* in_n = p.in + (long long)n * p.in_ns;
+    const SP<ST> in_n = SP<ST>(p.in) + (long long)n * p.in_ns;
     const int kmax = p.K - 1;
 #pragma unroll
     for (int i = 0; i < C::NPOS; ++i) {
@@ -886,7 +887,7 @@ __global__ __launch_bounds__(256, 3) void dgrad_loop_k(const IgemmParams p) {
         const int off = ok ? iy * p.Win + ix : 0;
         float v[16];
 #pragma unroll
-        for (int cc = 0; cc < 16; ++cc) v[cc] = in_n[(long long)min(cc, kmax) * p.in_cs + off];
+        for (int cc = 0; cc < 16; ++cc) v[cc] = in_n.ld1((long long)min(cc, kmax) * p.in_cs + off);
 #pragma unroll
         for (int cc = 0; cc < 16; ++cc) zl[cc * C::CHS + e] = (ok && cc <= kmax) ? v[cc] : 0.f;
       }
@@ -943,7 +944,7 @@ __global__ __launch_bounds__(256, 3) void dgrad_loop_k(const IgemmParams p) {
     pixoff[m] = (bits & 1u) ? gy * p.GW + gx : 0;  // clamped to a valid pixel when the whole group is outside
   }
   constexpr bool vec = VEC;
-  const float* Sn = p.S + (long long)n * p.s_ns;
+  const SP<ST> Sn = SP<ST>(p.S) + (long long)n * p.s_ns;
   float* Gn = p.out + (long long)n * p.out_ns;
   const float* zbase = zl + lk * C::CHS + ((wave * MPW * 16) / TW) * C::PITCH + lj;
   const int nct16 = ((p.J + 15) >> 4) * 16;
@@ -988,7 +989,7 @@ __global__ __launch_bounds__(256, 3) void dgrad_loop_k(const IgemmParams p) {
     const bool accum = (j >= p.acc_lo) && (j < p.acc_hi);
     // prefetch epilogue operands (clamped addresses; invalid lanes/pixels are masked in the epilogue)
     float sv[MPW][4], gv[MPW][4];
-    const float* Sc = Sn + (long long)jc * p.out_cs;
+    const SP<ST> Sc = Sn + (long long)jc * p.out_cs;
     float* Gc = Gn + (long long)jc * p.out_cs;
 #ifdef RLN_DIAG
     if (p.dbg & 1) {  // timing ablation: no S/G reads
@@ -1001,7 +1002,7 @@ __global__ __launch_bounds__(256, 3) void dgrad_loop_k(const IgemmParams p) {
     if constexpr (vec) {
 #pragma unroll
       for (int m = 0; m < MPW; ++m) {
-        const float4 t4 = *reinterpret_cast<const float4*>(Sc + pixoff[m]);
+        const float4 t4 = Sc.ld4(pixoff[m]);
         sv[m][0] = t4.x; sv[m][1] = t4.y; sv[m][2] = t4.z; sv[m][3] = t4.w;
         const float4 g4 = *reinterpret_cast<const float4*>(Gc + pixoff[m]);
         gv[m][0] = g4.x; gv[m][1] = g4.y; gv[m][2] = g4.z; gv[m][3] = g4.w;
@@ -1012,7 +1013,7 @@ __global__ __launch_bounds__(256, 3) void dgrad_loop_k(const IgemmParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const bool ok = (vmask >> (4 * m + r)) & 1u;
-          sv[m][r] = Sc[pixoff[m] + (ok ? r : 0)];
+          sv[m][r] = Sc.ld1(pixoff[m] + (ok ? r : 0));
           gv[m][r] = Gc[pixoff[m] + (ok ? r : 0)];
         }
     }
@@ -1104,12 +1105,12 @@ __global__ __launch_bounds__(256, 3) void dgrad_loop_k(const IgemmParams p) {
   }
 }
 
-template <int TH, int TW, bool VEC>
+template <int TH, int TW, bool VEC, int ST = ST_F32>
 static int dgrad_loop_launch_t(const IgemmParams& p, int N, hipStream_t stream) {
   using C = IgCfg<3, 1, PRO_RAW, EPI_DGRAD, TH, TW>;
   const int LDS = (C::IN_FLOATS + 2 * C::W_FLOATS + 4 * (((p.J + 15) >> 4) * 16) * 2) * 4;
   static bool attr_done = false;
-  auto kern = dgrad_loop_k<TH, TW, VEC>;
+  auto kern = dgrad_loop_k<TH, TW, VEC, ST>;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               96 * 1024);
@@ -1143,6 +1144,11 @@ static int dgrad_loop_launch_t(const IgemmParams& p, int N, hipStream_t stream) 
 // K (= dY channels) must be <= 16.  One stat-partial row per block.
 int dgrad_loop_launch(int tile, const IgemmParams& p, int N, hipStream_t stream) {
   if (p.K > 16 || p.ncls != 1) return -1;
+  if (p.st == ST_BF16) {  // bf16 dY / S planes: quads of pixels are 8-byte aligned (host-checked like out_vec)
+    if (!p.out_vec) return -4;
+    return tile == 0 ? dgrad_loop_launch_t<8, 32, true, ST_BF16>(p, N, stream)
+                     : dgrad_loop_launch_t<16, 16, true, ST_BF16>(p, N, stream);
+  }
   if (p.out_vec)
     return tile == 0 ? dgrad_loop_launch_t<8, 32, true>(p, N, stream) : dgrad_loop_launch_t<16, 16, true>(p, N, stream);
   return tile == 0 ? dgrad_loop_launch_t<8, 32, false>(p, N, stream) : dgrad_loop_launch_t<16, 16, false>(p, N, stream);

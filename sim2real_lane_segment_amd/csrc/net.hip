@@ -26,6 +26,7 @@
 #include "fc3.h"
 #include "igemm.h"
 #include "pointwise.h"
+#include "storage.h"
 
 using namespace rln;
 
@@ -79,8 +80,11 @@ struct Op {
 struct Level {
   int C = 0, H = 0, W = 0;
   int64_t stat_off = 0;  // into per-channel arrays
-  float* S = nullptr;
-  float* G = nullptr;
+  float* S = nullptr;    // activation stack; holds bf16 elements when st == ST_BF16 (storage.h): address it through sp()
+  float* G = nullptr;    // gradient stack (fp32 in every mode)
+  int st = 0;            // storage element type of S and of the finalised output gradients dY of this level
+  // channel `ch` of sample 0 of the activation stack
+  float* sp(long long ch) const { return st_at(S, ch * (long long)H * W, st); }
 };
 
 }  // namespace
@@ -168,6 +172,7 @@ struct rln_ctx {
   // dense-layer arithmetic (rln_set_dense_arith): 0 parts = exact fp32 MFMA kernels, else split 16-bit MFMA (dense3.h)
   int d3_fwd_np = 0, d3_fwd_dt = 0, d3_bwd_np = 0, d3_bwd_dt = 0;
   int wg_parts = 0;  // operand parts of the dense 3x3 weight-gradient GEMMs (rln_set_wgrad_parts)
+  int storage = 0;   // rln_set_storage: 0 = fp32 stacks, 1 = bf16 stacks on the levels the 16-bit kernel families cover
   std::vector<D3PackDesc> d3_desc_f, d3_desc_b;  // host copies, one entry per dense op
   std::vector<long long> d3_wf_off, d3_wb_off;   // per op index (uint4 units into d3_packed), -1: none
   D3PackDesc* d3_desc_f_dev = nullptr;
@@ -473,7 +478,14 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
   level_dims(c, h, w, hs, ws);
   Carver cv(base);
   std::vector<float*> S(nd + 1), G(nd + 1);
-  for (int L = 0; L <= nd; ++L) S[L] = cv.take<float>((size_t)n * c->levels[L].C * hs[L] * ws[L]);
+  // bf16 storage: the levels the split-operand kernel families cover (rows of >= 40 pixels in whole octets: 97.5 % of
+  // the activation elements at 120x160) keep their stack as bf16 planes; the deep levels stay fp32
+  std::vector<int> lst(nd + 1, ST_F32);
+  for (int L = 0; L <= nd; ++L)
+    if (c->storage == 1 && ws[L] >= 40 && (ws[L] % 8) == 0 && hs[L] >= 4 && c->cfg.growth_rate <= 16) lst[L] = ST_BF16;
+  for (int L = 0; L <= nd; ++L)
+    S[L] = reinterpret_cast<float*>(
+        cv.take<unsigned char>((size_t)n * c->levels[L].C * hs[L] * ws[L] * (size_t)st_bytes(lst[L])));
   for (int L = 0; L <= nd; ++L) G[L] = with_bwd ? cv.take<float>((size_t)n * c->levels[L].C * hs[L] * ws[L]) : nullptr;
   float* mean = cv.take<float>(c->n_chan);
   float* var = cv.take<float>(c->n_chan);
@@ -732,6 +744,7 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
       c->levels[L].W = ws[L];
       c->levels[L].S = S[L];
       c->levels[L].G = G[L];
+      c->levels[L].st = lst[L];
     }
     c->mean = mean;
     c->var = var;
@@ -872,7 +885,7 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
   p.bias = c->params + o.conv.b;
   p.nscale = (training && o.drop_ch >= 0) ? (c->masks + (size_t)N * o.drop_ch) : nullptr;
   p.stat_partial = training ? c->stat_partial : nullptr;
-  p.out = dl.S + (size_t)o.out_off * dl.H * dl.W;
+  p.out = dl.sp(o.out_off);
   p.out_ns = (long long)dl.C * dl.H * dl.W;
   p.out_cs = dl.H * dl.W;
   p.Hout = dl.H;
@@ -894,7 +907,7 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
   } else if (o.type == OP_DENSE) {
     kind = IG_CONV3_BN;
     RLN_TRY(prep_bn(c, o, training, s, (long long)k));
-    p.in = dl.S + (size_t)o.in_off * dl.H * dl.W;
+    p.in = dl.sp(o.in_off);
     p.in_ns = p.out_ns;
     p.in_cs = p.out_cs;
     p.Hin = dl.H;
@@ -909,7 +922,7 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
     kind = IG_CONV1_POOL;
     RLN_TRY(prep_bn(c, o, training, s, (long long)k));
     const Level& sl = c->levels[o.src_level];
-    p.in = sl.S + (size_t)o.in_off * sl.H * sl.W;
+    p.in = sl.sp(o.in_off);
     p.in_ns = (long long)sl.C * sl.H * sl.W;
     p.in_cs = sl.H * sl.W;
     p.Hin = sl.H;
@@ -924,7 +937,7 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
   } else {  // OP_TU: ConvTranspose2d by output parity class
     kind = IG_CONV3_RAW;
     const Level& sl = c->levels[o.src_level];
-    p.in = sl.S + (size_t)o.in_off * sl.H * sl.W;
+    p.in = sl.sp(o.in_off);
     p.in_ns = (long long)sl.C * sl.H * sl.W;
     p.in_cs = sl.H * sl.W;
     p.Hin = sl.H;
@@ -961,13 +974,14 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
     q.Cout = o.cout;
     q.stat_partial = p.stat_partial;
     q.ksplit = 1;
+    q.st = dl.st;
     if (d3_fwd_supported(q)) {
       d3_fwd_pick_tile(q.H, q.W, c->d3_fwd_np, &q.th, &q.tw, &q.rg);
       q.tiles_y = (q.H + q.th - 1) / q.th;
       q.tiles_x = (q.W + q.tw - 1) / q.tw;
       {
         const double flops = 2.0 * o.cin * o.cout * 9.0 * q.H * q.W * N;
-        const double bytes = 4.0 * N * ((double)o.cin + o.cout) * q.H * q.W;
+        const double bytes = (double)st_bytes(dl.st) * N * ((double)o.cin + o.cout) * q.H * q.W;
         ProfScope ps(c, PC_D3_FWD, flops, bytes, s);
         RLN_TRY(d3_fwd_launch(q, N, c->d3_fwd_np, c->d3_fwd_dt, s));
       }
@@ -992,11 +1006,12 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
     q.out_cs = p.out_cs;
     q.Cout = o.cout;
     q.stat_partial = p.stat_partial;
+    q.ot = dl.st;
     if (f3_fwd_supported(q)) {
       f3_fwd_plan(&q);
       {
         const double flops = 2.0 * o.cin * o.cout * 9.0 * dl.H * dl.W * N;
-        const double bytes = 4.0 * N * ((double)o.cin + o.cout) * dl.H * dl.W;
+        const double bytes = (double)N * (4.0 * o.cin + (double)st_bytes(dl.st) * o.cout) * dl.H * dl.W;
         ProfScope ps(c, PC_FIRST_FWD, flops, bytes, s);
         RLN_TRY(f3_fwd_launch(q, c->d3_fwd_np, c->d3_fwd_dt, s));
       }
@@ -1024,11 +1039,14 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
     q.Ho = dl.H;
     q.Wo = dl.W;
     q.stat_partial = p.stat_partial;
+    q.st = sl.st;
+    q.ot = dl.st;
     if (c3_fwd_supported(q) && c3_fwd_fits(q, c->d3_fwd_np)) {
       c3_fwd_plan(&q, c->d3_fwd_np);
       {
         const double flops = 2.0 * o.cin * o.cout * 9.0 * sl.H * sl.W * N;
-        const double bytes = 4.0 * N * ((double)o.cin * sl.H * sl.W + (double)o.cout * dl.H * dl.W);
+        const double bytes = (double)N * ((double)st_bytes(sl.st) * o.cin * sl.H * sl.W +
+                                          (double)st_bytes(dl.st) * o.cout * dl.H * dl.W);
         ProfScope ps(c, PC_TU_FWD, flops, bytes, s);
         RLN_TRY(c3_fwd_launch(q, c->d3_fwd_np, c->d3_fwd_dt, s));
       }
@@ -1058,11 +1076,14 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
     q.Cout = o.cout;
     q.pool_idx = p.pool_idx;
     q.stat_partial = p.stat_partial;
+    q.st = sl.st;
+    q.ot = dl.st;
     if (p1_fwd_supported(q) && dl.H == sl.H / 2 && dl.W == sl.W / 2) {
       p1_fwd_plan(&q, c->d3_fwd_np);
       {
         const double flops = 2.0 * o.cin * o.cout * sl.H * sl.W * N;
-        const double bytes = 4.0 * N * ((double)o.cin * sl.H * sl.W + 1.25 * o.cout * dl.H * dl.W);
+        const double bytes = (double)N * ((double)st_bytes(sl.st) * o.cin * sl.H * sl.W +
+                                          ((double)st_bytes(dl.st) + 1.0) * o.cout * dl.H * dl.W);
         ProfScope ps(c, PC_TD_FWD, flops, bytes, s);
         RLN_TRY(p1_fwd_launch(q, c->d3_fwd_np, c->d3_fwd_dt, s));
       }
@@ -1070,6 +1091,10 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
       return 0;
     }
   }
+  // the exact-fp32 family below reads and writes fp32 stacks only
+  if (dl.st != ST_F32 || (o.src_level >= 0 && c->levels[o.src_level].st != ST_F32))
+    return fail(RLN_ERR_UNSUPPORTED, "op %zu: geometry not covered by the bf16-storage kernels (level %d -> %d)", k,
+                o.src_level, o.dst_level);
   tile = igemm_pick_tile(p.GH, p.GW);
   if (kind == IG_CONV3_BN && igemm_pick_strip_tile(p.GW) >= 0 && aligned16(p.in) && (p.in_cs % 4) == 0 &&
       (p.in_ns % 4) == 0)
@@ -1123,6 +1148,7 @@ HeadParams head_params(rln_ctx* c) {
   h.w = c->params + c->cls.w;
   h.b = c->params + c->cls.b;
   h.T = c->cfg.temperature;
+  h.st = l0.st;
   return h;
 }
 
@@ -1136,7 +1162,7 @@ int finalize_grad_range(rln_ctx* c, int level, int ch_off, int C, const float* n
   GradFinParams g;
   memset(&g, 0, sizeof(g));
   const size_t plane = (size_t)lv.H * lv.W;
-  g.S = lv.S + ch_off * plane;
+  g.S = lv.sp(ch_off);
   g.G = lv.G + ch_off * plane;
   g.ns = (long long)lv.C * plane;
   g.C = C;
@@ -1153,7 +1179,8 @@ int finalize_grad_range(rln_ctx* c, int level, int ch_off, int C, const float* n
   g.bias_partial = c->bpartial;
   g.Hd = lv.H;
   g.Wd = lv.W;
-  ProfScope ps(c, PC_GRADFIN, 0, 12.0 * c->N * C * plane, s);
+  g.st = lv.st;
+  ProfScope ps(c, PC_GRADFIN, 0, (4.0 + 2.0 * st_bytes(lv.st)) * c->N * C * plane, s);
   RLN_TRY(grad_finalize(g, c->N, rows, s));
   return 0;
 }
@@ -1277,8 +1304,9 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
       p.out_cs = (int)plane;
       p.Hout = lv.H;
       p.Wout = lv.W;
-      p.S = lv.S + (size_t)o.in_off * plane;
+      p.S = lv.sp(o.in_off);
       p.s_ns = p.out_ns;
+      p.st = lv.st;
       const int64_t so = lv.stat_off + o.in_off;
       p.ea = c->ab + o.bn.ab;
       p.eb = c->ab + c->n_ab + o.bn.ab;
@@ -1288,6 +1316,8 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
       p.acc_lo = o.acc_lo;
       p.acc_hi = o.acc_hi;
       p.stat_partial = c->stat_partial;
+      if (lv.st != ST_F32 && o.cout > 16)
+        return fail(RLN_ERR_UNSUPPORTED, "bf16 storage needs growth_rate <= 16");
       const int tile = igemm_pick_tile(p.GH, p.GW);
       int th, tw;
       igemm_tile_dims(IG_DGRAD3, tile, &th, &tw);
@@ -1336,8 +1366,10 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
     w.m_stride = (long long)o.cin * 9;
     w.n_stride = 9;
     RLN_TRY(wg_begin(c, s, &ws));
+    if (o.type == OP_DENSE && lv.st != ST_F32)
+      return fail(RLN_ERR_UNSUPPORTED, "op %zu: dense block not covered by the bf16-storage backward kernels", k);
     if (o.type == OP_DENSE) {
-      w.v = lv.S + (size_t)o.in_off * plane;
+      w.v = lv.sp(o.in_off);
       w.v_ns = (long long)lv.C * plane;
       w.pa = c->ab + o.bn.ab;
       w.pb = c->ab + c->n_ab + o.bn.ab;
@@ -1370,6 +1402,7 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
         g.dY = c->dY;
         g.Cout = o.cout;
         g.partial = c->wpartial;
+        g.yt = lv.st;
         if (f3_wgrad_supported(g)) {
           f3_wgrad_plan(&g);
           {
@@ -1383,6 +1416,8 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
           done = true;
         }
       }
+      if (!done && lv.st != ST_F32)
+        return fail(RLN_ERR_UNSUPPORTED, "first convolution not covered by the bf16-storage weight-gradient kernel");
       if (!done) {
         w.v = c->last_x;
         w.v_ns = (long long)o.cin * plane;
@@ -1408,7 +1443,7 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
       q.egamma = c->params + o.bn.gamma;
       q.mean = c->mean + so;
       q.invstd = c->invstd + so;
-      q.S = sl.S + (size_t)o.in_off * splane;
+      q.S = sl.sp(o.in_off);
       q.ns = (long long)sl.C * splane;
       q.cs = (int)splane;
       q.G = sl.G + (size_t)o.in_off * splane;
@@ -1419,6 +1454,8 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
       q.W = sl.W;
       q.N = N;
       q.stat_partial = c->stat_partial;
+      q.st = sl.st;
+      q.yt = dl.st;
       P1Wgrad g;
       memset(&g, 0, sizeof(g));
       g.dYp = c->dY;
@@ -1434,11 +1471,13 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
       g.pa = q.ea;
       g.pb = q.eb;
       g.partial = c->wpartial;
+      g.st = sl.st;
+      g.yt = dl.st;
       if (p1_dgrad_supported(q) && p1_wgrad_supported(g)) {
         {  // finalise the pooled gradient (BatchNorm-backward correction of the level below, Dropout2d scale)
           GradFinParams f;
           memset(&f, 0, sizeof(f));
-          f.S = dl.S + (size_t)o.out_off * dplane;
+          f.S = dl.sp(o.out_off);
           f.G = dl.G + (size_t)o.out_off * dplane;
           f.ns = (long long)dl.C * dplane;
           f.C = o.cout;
@@ -1455,7 +1494,8 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
           f.bias_partial = c->bpartial;
           f.Hd = dl.H;
           f.Wd = dl.W;
-          ProfScope ps(c, PC_GRADFIN, 0, 12.0 * N * o.cout * dplane, s);
+          f.st = dl.st;
+          ProfScope ps(c, PC_GRADFIN, 0, (4.0 + 2.0 * st_bytes(dl.st)) * N * o.cout * dplane, s);
           RLN_TRY(grad_finalize(f, N, &rows, s));
         }
         p1_dgrad_plan(&q, c->d3_bwd_np);
@@ -1499,10 +1539,12 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
         return 0;
       }
     }
+    if (sl.st != ST_F32 || dl.st != ST_F32)
+      return fail(RLN_ERR_UNSUPPORTED, "op %zu: transition down not covered by the bf16-storage backward kernels", k);
     {  // pooled gradient -> pre-pool map (MaxPool2d backward) with the Dropout2d scale
       GradFinParams g;
       memset(&g, 0, sizeof(g));
-      g.S = dl.S + (size_t)o.out_off * dplane;
+      g.S = dl.sp(o.out_off);
       g.G = dl.G + (size_t)o.out_off * dplane;
       g.ns = (long long)dl.C * dplane;
       g.C = o.cout;
@@ -1545,7 +1587,7 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
     p.out_cs = (int)splane;
     p.Hout = sl.H;
     p.Wout = sl.W;
-    p.S = sl.S + (size_t)o.in_off * splane;
+    p.S = sl.sp(o.in_off);
     p.s_ns = p.out_ns;
     const int64_t so = sl.stat_off + o.in_off;
     p.ea = c->ab + o.bn.ab;
@@ -1578,7 +1620,7 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
     w.Uc = o.cout;
     w.GH = sl.H;
     w.GW = sl.W;
-    w.v = sl.S + (size_t)o.in_off * splane;
+    w.v = sl.sp(o.in_off);
     w.v_ns = (long long)sl.C * splane;
     w.v_cs = (int)splane;
     w.Vc = o.cin;
@@ -1643,6 +1685,7 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
       q.W = sl.W;
       q.C = o.cin;
       q.N = N;
+      q.yt = dl.st;
       if (c3_dgrad_supported(q)) {
         c3_dgrad_plan(&q);
         const double flops = 2.0 * o.cin * o.cout * 9.0 * splane * N;
@@ -1652,6 +1695,8 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
         dgrad_done = true;
       }
     }
+    if (!dgrad_done && dl.st != ST_F32)
+      return fail(RLN_ERR_UNSUPPORTED, "op %zu: transition up not covered by the bf16-storage data-gradient kernel", k);
     if (!dgrad_done) {
       const double flops = 2.0 * o.cin * o.cout * 9.0 * splane * N;
       const double bytes = 4.0 * N * ((double)o.cout * dplane + (double)o.cin * splane);
@@ -1661,7 +1706,7 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
     if (c->d3_bwd_np > 0) {
       C3Wgrad g;
       memset(&g, 0, sizeof(g));
-      g.X = sl.S + (size_t)o.in_off * splane;
+      g.X = sl.sp(o.in_off);
       g.ns = (long long)sl.C * splane;
       g.cs = (int)splane;
       g.H = sl.H;
@@ -1673,6 +1718,8 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
       g.Ho = dl.H;
       g.Wo = dl.W;
       g.partial = c->wpartial;
+      g.st = sl.st;
+      g.yt = dl.st;
       if (c3_wgrad_supported(g)) {
         c3_wgrad_plan(&g);
         RLN_TRY(wg_begin(c, s, &ws));
@@ -1700,10 +1747,12 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
         return 0;
       }
     }
+    if (sl.st != ST_F32 || dl.st != ST_F32)
+      return fail(RLN_ERR_UNSUPPORTED, "op %zu: transition up not covered by the bf16-storage weight-gradient kernel", k);
     RLN_TRY(reduce_rows(c->bpartial, rows, o.cout, c->grads + o.conv.b, s));
     WgradParams w;
     memset(&w, 0, sizeof(w));
-    w.u = sl.S + (size_t)o.in_off * splane;  // convT input (raw)
+    w.u = sl.sp(o.in_off);  // convT input (raw)
     w.u_ns = (long long)sl.C * splane;
     w.u_cs = (int)splane;
     w.Uc = o.cin;
@@ -1748,7 +1797,7 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
   q.Cout = first.cout;
   q.mean = c->mean + lv.stat_off + first.in_off;
   q.invstd = c->invstd + lv.stat_off + first.in_off;
-  q.S = lv.S + (size_t)first.in_off * plane;
+  q.S = lv.sp(first.in_off);
   q.G = lv.G + (size_t)first.in_off * plane;
   q.s_ns = (long long)lv.C * plane;
   q.cs = (int)plane;
@@ -1756,6 +1805,7 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
   q.H = lv.H;
   q.W = lv.W;
   q.N = N;
+  q.st = lv.st;
   q.nl = std::min(L, D3_LMAX);
   for (int i = 0; i < q.nl; ++i) q.dY[i] = c->dyblk[(size_t)i];
   d3_pull_pick_tile(q.H, q.W, &q.th, &q.tw);
@@ -1792,7 +1842,7 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
       w.wsize = (long long)o.cout * o.cin * 9;
       w.m_stride = (long long)o.cin * 9;
       w.n_stride = 9;
-      w.v = lv.S + (size_t)o.in_off * plane;
+      w.v = lv.sp(o.in_off);
       w.v_ns = (long long)lv.C * plane;
       w.pa = c->ab + o.bn.ab;
       w.pb = c->ab + c->n_ab + o.bn.ab;
@@ -1810,6 +1860,9 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
       g.Cout = o.cout;
       g.N = N;
       g.partial = c->wpartial;
+      g.st = lv.st;
+      if (lv.st != ST_F32 && !d3_wgrad_supported(g))
+        return fail(RLN_ERR_UNSUPPORTED, "dense weight gradient not covered by the bf16-storage kernel");
       if (d3_wgrad_supported(g)) {  // transposed-read 16-bit MFMA kernel
         d3_wgrad_plan(lv.H, lv.W, N, o.cin, &g);
 #ifdef RLN_DIAG
@@ -1858,8 +1911,9 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
       p.out_cs = (int)plane;
       p.Hout = lv.H;
       p.Wout = lv.W;
-      p.S = lv.S + (size_t)(o.in_off + C0) * plane;
+      p.S = lv.sp((o.in_off + C0));
       p.s_ns = p.out_ns;
+      p.st = lv.st;
       const int64_t so = lv.stat_off + o.in_off + C0;
       p.ea = c->ab + o.bn.ab + C0;
       p.eb = c->ab + c->n_ab + o.bn.ab + C0;
@@ -2021,6 +2075,8 @@ int rln_set_dense_arith(rln_ctx* c, int fwd_parts, int fwd_dtype, int bwd_parts,
   auto bad = [](int np, int dt) { return np < 0 || np > 3 || dt < 0 || dt > 1 || (dt == 1 && np == 3); };
   if (bad(fwd_parts, fwd_dtype) || bad(bwd_parts, bwd_dtype))
     return fail(RLN_ERR_ARG, "parts in 0..3 (f16: 0..2), dtype 0 (bf16) or 1 (f16)");
+  if (c->storage == 1 && (fwd_parts != 1 || bwd_parts != 1 || fwd_dtype != D3_BF16 || bwd_dtype != D3_BF16))
+    return fail(RLN_ERR_ARG, "bf16 storage runs on one-part bf16 operands (rln_set_storage(ctx, 0) first)");
   c->d3_fwd_np = fwd_parts;
   c->d3_fwd_dt = fwd_dtype;
   c->d3_bwd_np = bwd_parts;
@@ -2030,6 +2086,20 @@ int rln_set_dense_arith(rln_ctx* c, int fwd_parts, int fwd_dtype, int bwd_parts,
   c->N = c->H = c->W = 0;
   return 0;
 }
+
+int rln_set_storage(rln_ctx* c, int mode) {
+  if (mode != 0 && mode != 1) return fail(RLN_ERR_ARG, "storage mode 0 (fp32 stacks) or 1 (bf16 stacks)");
+  c->storage = mode;
+  if (mode == 1) {  // bf16 stacks are read as plain bf16 MFMA operands everywhere (fp32 accumulation and statistics)
+    c->d3_fwd_np = c->d3_bwd_np = c->wg_parts = 1;
+    c->d3_fwd_dt = c->d3_bwd_dt = D3_BF16;
+  }
+  c->levels[0].S = nullptr;  // the workspace layout depends on the mode: it has to be set again
+  c->N = c->H = c->W = 0;
+  return 0;
+}
+int rln_get_storage(const rln_ctx* c) { return c->storage; }
+int rln_get_wgrad_parts(const rln_ctx* c) { return c->wg_parts; }
 
 int rln_set_wgrad_parts(rln_ctx* c, int parts) {
   if (parts < 0 || parts > 3) return fail(RLN_ERR_ARG, "parts in 0..3 (0 = as many as the backward arithmetic)");
@@ -2151,6 +2221,7 @@ int rln_classifier_forward(rln_ctx* c, const float* feat, int n, int h, int w, f
                            void* stream) {
   if (!c->params) return fail(RLN_ERR_STATE, "rln_bind_params not called");
   HeadParams hp;
+  hp.st = ST_F32;
   hp.S = feat;
   hp.C = c->feat_C;
   hp.HW = h * w;
@@ -2267,6 +2338,8 @@ int rln_backward_scaled(rln_ctx* c, float loss_scale, const float* loss_scale_de
     q.bias_partial = c->bpartial;
     long long rows = 0;
     ProfScope ps(c, PC_HEAD_BWD, 2.0 * N * q.h.HW * q.h.C * (3.0 * q.h.ncls + 2), 4.0 * N * q.h.HW * 2.0 * q.h.C, s);
+    if (q.h.C > 512 && q.h.st != ST_F32)
+      return fail(RLN_ERR_UNSUPPORTED, "bf16 storage needs <= 512 feature channels in the head backward");
     if (q.h.C <= 512) {  // one pass over the feature stack
       RLN_TRY(head_backward_fused(q, N, c->wpartial, &rows, s));
       RLN_TRY(reduce_rows(c->bpartial, rows, c->cfg.n_classes, c->grads + c->cls.b, s));
@@ -2928,6 +3001,7 @@ int rln_op_dropout_mask(float* dst, int64_t count, float keep, uint64_t seed, vo
 int rln_op_classifier(const float* feat, int n, int c, int hw, const float* w, const float* b, int ncls, float T,
                       float* out, int use_softmax, void* stream) {
   HeadParams hp;
+  hp.st = ST_F32;
   hp.S = feat;
   hp.C = c;
   hp.HW = hw;

@@ -41,6 +41,7 @@ struct GradFinParams {
   // pool-backward variant: dst is the pre-pool map (Hd x Wd), S/G are the pooled maps (H x W)
   const unsigned char* pool_idx;  // [N][C][H][W] or null
   int Hd, Wd;
+  int st;  // storage element type of S and of dst (storage.h); G is fp32
 };
 // returns number of bias_partial rows through *rows
 int grad_finalize(const GradFinParams& p, int N, long long* rows, hipStream_t s);
@@ -71,6 +72,7 @@ struct HeadParams {
   const float* w;  // [ncls][C]
   const float* b;  // [ncls]
   float T;
+  int st;  // storage element type of S (storage.h)
 };
 int head_forward(const HeadParams& p, int N, float* out, int use_softmax, float* feat_out, hipStream_t s);
 // classifier alone on given features [N][C][HW] contiguous

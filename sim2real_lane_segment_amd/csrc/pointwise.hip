@@ -2,6 +2,7 @@
 // that are coalesced along the pixel axis of NCHW planes, wave64 shuffles for reductions, block
 // partials + fixed-order second stage instead of float atomics (bitwise reproducible results).
 #include "pointwise.h"
+#include "storage.h"
 
 #include <cstring>
 
@@ -191,6 +192,7 @@ int bn_bwd_finalize(const float* partial, long long nblk, int J, const float* ga
 // gradient finalisation:  d/dx = invstd * (G - S1/M - xhat * S2/M)  [* dropout scale]
 // =============================================================================================
 
+template <int ST>  // storage element type of S and of dst (the level's activations and its finalised gradients)
 __global__ __launch_bounds__(256) void grad_finalize_k(const GradFinParams p) {
   const int c = blockIdx.y, n = blockIdx.z;
   const int tid = threadIdx.x;
@@ -199,10 +201,10 @@ __global__ __launch_bounds__(256) void grad_finalize_k(const GradFinParams p) {
   float sc = 1.f;
   if (p.nscale != nullptr) sc = p.nscale[(long long)n * p.C + c];
   const long long plane = (long long)p.H * p.W;
-  const float* Sp = p.S + (long long)n * p.ns + (long long)c * plane;
+  const SP<ST> Sp = SP<ST>(p.S) + ((long long)n * p.ns + (long long)c * plane);
   const float* Gp = p.G + (long long)n * p.ns + (long long)c * plane;
   const long long dplane = (long long)p.Hd * p.Wd;
-  float* dp = p.dst + ((long long)n * p.C + c) * dplane;
+  const SP<ST> dp = SP<ST>(p.dst) + ((long long)n * p.C + c) * dplane;
   float bsum = 0.f;
   const long long e0 = (long long)blockIdx.x * 1024;
   if (p.pool_idx == nullptr) {
@@ -210,9 +212,9 @@ __global__ __launch_bounds__(256) void grad_finalize_k(const GradFinParams p) {
     for (int i = 0; i < 4; ++i) {
       const long long e = e0 + i * 256 + tid;
       if (e < dplane) {
-        const float xh = (Sp[e] - mean) * is;
-        const float v = sc * is * (Gp[e] - k1 - xh * k2);
-        dp[e] = v;
+        const float xh = (Sp.ld1(e) - mean) * is;
+        const float v = st_round<ST>(sc * is * (Gp[e] - k1 - xh * k2));  // the bias gradient sums what is stored
+        dp.st1(e, v);
         bsum += v;
       }
     }
@@ -228,11 +230,11 @@ __global__ __launch_bounds__(256) void grad_finalize_k(const GradFinParams p) {
         if (py < p.H && px < p.W) {
           const long long q = (long long)py * p.W + px;
           if ((int)ip[q] == (((yd & 1) << 1) | (xd & 1))) {
-            const float xh = (Sp[q] - mean) * is;
-            v = sc * is * (Gp[q] - k1 - xh * k2);
+            const float xh = (Sp.ld1(q) - mean) * is;
+            v = st_round<ST>(sc * is * (Gp[q] - k1 - xh * k2));
           }
         }
-        dp[e] = v;
+        dp.st1(e, v);
         bsum += v;
       }
     }
@@ -257,7 +259,10 @@ long long grad_finalize_rows(int N, int Hd, int Wd) {
 int grad_finalize(const GradFinParams& p, int N, long long* rows, hipStream_t s) {
   const long long nbx = ((long long)p.Hd * p.Wd + 1023) / 1024;
   if (rows) *rows = nbx * N;
-  hipLaunchKernelGGL(grad_finalize_k, dim3((unsigned)nbx, (unsigned)p.C, (unsigned)N), dim3(256), 0, s, p);
+  if (p.st == ST_BF16)
+    hipLaunchKernelGGL(grad_finalize_k<ST_BF16>, dim3((unsigned)nbx, (unsigned)p.C, (unsigned)N), dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL(grad_finalize_k<ST_F32>, dim3((unsigned)nbx, (unsigned)p.C, (unsigned)N), dim3(256), 0, s, p);
   RLN_LAUNCH_CHECK();
 }
 
@@ -417,7 +422,7 @@ __device__ __forceinline__ void softmax_nc(float* l, int ncls) {
 }
 
 // NORMALIZE: input is the raw stack (fused feature extractor tail); else input already normalised
-template <int NC, bool NORMALIZE>
+template <int NC, bool NORMALIZE, int ST>
 __global__ __launch_bounds__(256) void head_fwd_k(const HeadParams p, float* out, int use_softmax, float* feat_out) {
   extern __shared__ __align__(16) float hsm[];
   float* wt = hsm;
@@ -427,14 +432,14 @@ __global__ __launch_bounds__(256) void head_fwd_k(const HeadParams p, float* out
   const int n = blockIdx.y;
   const long long px = (long long)blockIdx.x * 256 + threadIdx.x;
   if (px >= p.HW) return;
-  const float* xp = p.S + (long long)n * p.ns + px;
+  const SP<ST> xp = SP<ST>(p.S) + ((long long)n * p.ns + px);
   float d[NC];
 #pragma unroll
   for (int k = 0; k < NC; ++k) d[k] = 0.f;
   float ss = 0.f;
 #pragma unroll 8
   for (int c = 0; c < p.C; ++c) {
-    const float x = xp[(long long)c * p.HW];
+    const float x = xp.ld1((long long)c * p.HW);
     ss = fmaf(x, x, ss);
 #pragma unroll
     for (int k = 0; k < NC; ++k) d[k] = fmaf(wt[c * NC + k], x, d[k]);
@@ -453,7 +458,7 @@ __global__ __launch_bounds__(256) void head_fwd_k(const HeadParams p, float* out
   if (feat_out != nullptr) {
     float* fp = feat_out + (long long)n * p.C * p.HW + px;
 #pragma unroll 8
-    for (int c = 0; c < p.C; ++c) fp[(long long)c * p.HW] = xp[(long long)c * p.HW] * inv;
+    for (int c = 0; c < p.C; ++c) fp[(long long)c * p.HW] = xp.ld1((long long)c * p.HW) * inv;
   }
 }
 
@@ -461,14 +466,25 @@ template <bool NORMALIZE>
 static int head_launch(const HeadParams& p, int N, float* out, int use_softmax, float* feat_out, hipStream_t s) {
   if (p.C > HEAD_MAXC || p.ncls > 16 || p.ncls < 1) return -4;
   dim3 grid((unsigned)((p.HW + 255) / 256), (unsigned)N);
-  if (p.ncls <= 4) {
-    hipLaunchKernelGGL((head_fwd_k<4, NORMALIZE>), grid, dim3(256), (p.C * 4 + 4) * 4, s, p, out, use_softmax,
+  if (p.st == ST_BF16) {
+    if (p.ncls <= 4) {
+      hipLaunchKernelGGL((head_fwd_k<4, NORMALIZE, ST_BF16>), grid, dim3(256), (p.C * 4 + 4) * 4, s, p, out, use_softmax,
+                         feat_out);
+    } else if (p.ncls <= 8) {
+      hipLaunchKernelGGL((head_fwd_k<8, NORMALIZE, ST_BF16>), grid, dim3(256), (p.C * 8 + 8) * 4, s, p, out, use_softmax,
+                         feat_out);
+    } else {
+      hipLaunchKernelGGL((head_fwd_k<16, NORMALIZE, ST_BF16>), grid, dim3(256), (p.C * 16 + 16) * 4, s, p, out,
+                         use_softmax, feat_out);
+    }
+  } else if (p.ncls <= 4) {
+    hipLaunchKernelGGL((head_fwd_k<4, NORMALIZE, ST_F32>), grid, dim3(256), (p.C * 4 + 4) * 4, s, p, out, use_softmax,
                        feat_out);
   } else if (p.ncls <= 8) {
-    hipLaunchKernelGGL((head_fwd_k<8, NORMALIZE>), grid, dim3(256), (p.C * 8 + 8) * 4, s, p, out, use_softmax,
+    hipLaunchKernelGGL((head_fwd_k<8, NORMALIZE, ST_F32>), grid, dim3(256), (p.C * 8 + 8) * 4, s, p, out, use_softmax,
                        feat_out);
   } else {
-    hipLaunchKernelGGL((head_fwd_k<16, NORMALIZE>), grid, dim3(256), (p.C * 16 + 16) * 4, s, p, out, use_softmax,
+    hipLaunchKernelGGL((head_fwd_k<16, NORMALIZE, ST_F32>), grid, dim3(256), (p.C * 16 + 16) * 4, s, p, out, use_softmax,
                        feat_out);
   }
   RLN_LAUNCH_CHECK();
@@ -801,7 +817,7 @@ constexpr int HEAD_TPX = 32;   // pixels per tile
 constexpr int HEAD_TPB = 10;   // tiles per block
 constexpr int HEAD_XS = 33;    // LDS row stride of the staged tile (odd: conflict-free for both access patterns)
 
-template <int NC>
+template <int NC, int ST>  // ST: storage element type of the feature stack
 __global__ __launch_bounds__(256) void head_bwd_fused_k(const HeadBwdParams q, float* __restrict__ wpartial) {
   const float ls = q.loss_scale * (q.loss_scale_dev ? *q.loss_scale_dev : 1.f);  // d(loss) from autograd stays on the device
   const HeadParams& p = q.h;
@@ -816,7 +832,7 @@ __global__ __launch_bounds__(256) void head_bwd_fused_k(const HeadBwdParams q, f
   for (int e = threadIdx.x; e < p.C; e += 256) sdt[e] = 1.f / q.invstd[e];
   const int tid = threadIdx.x, pl = tid & 31, g = tid >> 5;
   const int n = blockIdx.y;
-  const float* Sn = p.S + (long long)n * p.ns;
+  const SP<ST> Sn = SP<ST>(p.S) + (long long)n * p.ns;
   float* Gn = q.G + (long long)n * q.g_ns;
   float wacc[2][NC], bsum[NC];
 #pragma unroll
@@ -834,7 +850,7 @@ __global__ __launch_bounds__(256) void head_bwd_fused_k(const HeadBwdParams q, f
     for (int k = 0; k < NC; ++k) d[k] = 0.f;
 #pragma unroll 18
     for (int c = g; c < p.C; c += 8) {
-      const float x = Sn[(long long)c * p.HW + pxs];
+      const float x = Sn.ld1((long long)c * p.HW + pxs);
       xs[c * HEAD_XS + pl] = x;
       ss = fmaf(x, x, ss);
 #pragma unroll
@@ -962,20 +978,26 @@ int head_backward_fused(const HeadBwdParams& q, int N, float* wpartial, long lon
   auto lds = [&](int nc) {
     return (size_t)(p.C * nc + nc + 8 * (1 + nc) * HEAD_TPX + nc * HEAD_TPX + p.C * HEAD_XS + p.C) * 4;
   };
-#define RLN_HEAD_FUSED(NCV)                                                                                         \
+#define RLN_HEAD_FUSED(NCV, STV)                                                                                    \
   {                                                                                                                 \
     static bool attr = false;                                                                                       \
     if (!attr) {                                                                                                    \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head_bwd_fused_k<NCV>),                               \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head_bwd_fused_k<NCV, STV>),                          \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);                            \
       (void)hipGetLastError();                                                                                      \
       attr = true;                                                                                                  \
     }                                                                                                               \
-    hipLaunchKernelGGL(head_bwd_fused_k<NCV>, grid, dim3(256), lds(NCV), s, q, wpartial);                           \
+    hipLaunchKernelGGL((head_bwd_fused_k<NCV, STV>), grid, dim3(256), lds(NCV), s, q, wpartial);                    \
   }
-  if (p.ncls <= 4) RLN_HEAD_FUSED(4)
-  else if (p.ncls <= 8) RLN_HEAD_FUSED(8)
-  else RLN_HEAD_FUSED(16)
+  if (p.st == ST_BF16) {
+    if (p.ncls <= 4) RLN_HEAD_FUSED(4, ST_BF16)
+    else if (p.ncls <= 8) RLN_HEAD_FUSED(8, ST_BF16)
+    else RLN_HEAD_FUSED(16, ST_BF16)
+  } else {
+    if (p.ncls <= 4) RLN_HEAD_FUSED(4, ST_F32)
+    else if (p.ncls <= 8) RLN_HEAD_FUSED(8, ST_F32)
+    else RLN_HEAD_FUSED(16, ST_F32)
+  }
 #undef RLN_HEAD_FUSED
   RLN_LAUNCH_CHECK();
 }

@@ -49,6 +49,7 @@ struct P1Fwd {
   float* stat_partial;      // [bpg][Cout][2] or null
   int mt, groups, bpg;      // M tiles per block, output-channel groups, blocks per group (p1_fwd_plan)
   int dbg;                  // diagnostic builds (-DRLN_DIAG) only: 1 no global loads, 2 no MFMA phase, 4 no epilogue
+  int st, ot;               // storage element types of S and of out (storage.h)
 };
 bool p1_fwd_supported(const P1Fwd& p);
 void p1_fwd_plan(P1Fwd* p, int np);  // fills mt, groups, bpg from Cin, Cout, N, H, W
@@ -73,6 +74,7 @@ struct P1Dgrad {
   int H, W, N;
   float* stat_partial;  // [bpg][C][2]: sum gz, sum gz * xhat
   int mt, groups, bpg;
+  int st, yt;  // storage element types of S and of dYp (storage.h); G is fp32
 };
 bool p1_dgrad_supported(const P1Dgrad& p);
 void p1_dgrad_plan(P1Dgrad* p, int np);
@@ -91,6 +93,7 @@ struct P1Wgrad {
   float* partial;  // [nranges][Cout][Cin]
   int mo;          // M tiles (16 output channels each) per block
   int ogroups, cblocks, nranges, per;  // output-channel groups, 128-input-channel blocks, K ranges of `per` slabs
+  int st, yt;      // storage element types of S and of dYp (storage.h)
 };
 bool p1_wgrad_supported(const P1Wgrad& p);
 void p1_wgrad_plan(P1Wgrad* p);  // fills mo, ogroups, cblocks, nranges, per

@@ -5,6 +5,7 @@
 #include <cstdio>
 
 #include "split16.h"
+#include "storage.h"
 
 namespace rln {
 
@@ -93,7 +94,7 @@ static void p1_group_plan(int m_tiles, int ksteps, int np, int extra_bytes_per_m
 // MaxPool2d), pooled value and argmax stored, per-channel sums of the pooled map reduced over the 16 windows with DPP
 // and accumulated in the wave's own LDS slots (fixed order: deterministic).
 // =============================================================================================
-template <int NP, int DT>
+template <int NP, int DT, int ST, int OT>
 __global__ __launch_bounds__(512, 2) void p1_fwd_k(const P1Fwd p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(512, 2) void p1_fwd_k(const P1Fwd p) {
   const int tstride = p.bpg * 8;
 
   struct Tile {
-    const float* base;
+    SP<ST> base;
     int ns_, poff;
     bool valid;
   };
@@ -137,21 +138,22 @@ __global__ __launch_bounds__(512, 2) void p1_fwd_k(const P1Fwd p) {
     t.ns_ = v / PP;
     t.poff = v - t.ns_ * PP;
     const int wy = t.poff / PW, wx = t.poff - wy * PW;
-    t.base = p.S + (long long)t.ns_ * p.ns + (long long)(2 * wy) * p.W + 2 * wx;
+    t.base = SP<ST>(p.S) + ((long long)t.ns_ * p.ns + (long long)(2 * wy) * p.W + 2 * wx);
     return t;
   };
 
-  float2 r0[8], r1[8];
-  auto issue = [&](const float* base, int ks) __attribute__((always_inline)) {
+  typename SRaw<ST>::r2 q0[8], q1[8];  // raw window rows (narrow until convert widens them)
+  auto issue = [&](const SP<ST> base, int ks) __attribute__((always_inline)) {
     // Cin % 8 == 0: an 8-channel block is all-in or all-out; blocks past Cin re-read the last block (their folded
     // scale / shift in abtab is zero, so they contribute relu(0) = 0)
-    const float* q = base + (long long)min(ks * 32 + kb * 8, p.Cin - 8) * p.cs;
+    const SP<ST> q = base + (long long)min(ks * 32 + kb * 8, p.Cin - 8) * p.cs;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      r0[e] = *reinterpret_cast<const float2*>(q + e * p.cs);
-      r1[e] = *reinterpret_cast<const float2*>(q + e * p.cs + p.W);
+      q0[e] = q.raw2((long long)e * p.cs);
+      q1[e] = q.raw2((long long)e * p.cs + p.W);
     }
   };
+  bool dbg_const = false;
   uint4 bf[4][NP];
   auto convert = [&](int ks) __attribute__((always_inline)) {
     const float4* ap = reinterpret_cast<const float4*>(abtab + ks * 32 + kb * 8);
@@ -162,10 +164,12 @@ __global__ __launch_bounds__(512, 2) void p1_fwd_k(const P1Fwd p) {
     float z[4][8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      z[0][e] = fmaxf(fmaf(av[e], r0[e].x, bv[e]), 0.f);
-      z[1][e] = fmaxf(fmaf(av[e], r0[e].y, bv[e]), 0.f);
-      z[2][e] = fmaxf(fmaf(av[e], r1[e].x, bv[e]), 0.f);
-      z[3][e] = fmaxf(fmaf(av[e], r1[e].y, bv[e]), 0.f);
+      const float2 r0 = dbg_const ? make_float2(0.5f, -0.25f) : SRaw<ST>::w2(q0[e]);
+      const float2 r1 = dbg_const ? make_float2(0.5f, -0.25f) : SRaw<ST>::w2(q1[e]);
+      z[0][e] = fmaxf(fmaf(av[e], r0.x, bv[e]), 0.f);
+      z[1][e] = fmaxf(fmaf(av[e], r0.y, bv[e]), 0.f);
+      z[2][e] = fmaxf(fmaf(av[e], r1.x, bv[e]), 0.f);
+      z[3][e] = fmaxf(fmaf(av[e], r1.y, bv[e]), 0.f);
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -182,10 +186,7 @@ __global__ __launch_bounds__(512, 2) void p1_fwd_k(const P1Fwd p) {
 #else
   constexpr int dbg = 0;
 #endif
-  if (dbg & 1) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) r0[e] = r1[e] = make_float2(0.5f, -0.25f);
-  }
+  if (dbg & 1) dbg_const = true;
   const bool sc_vec = (reinterpret_cast<uintptr_t>(p.nscale) & 15) == 0;
   f32x4 acc[8][4];
   int T = b * 8 + wave;
@@ -269,8 +270,9 @@ __global__ __launch_bounds__(512, 2) void p1_fwd_k(const P1Fwd p) {
             }
           }
           const bool st = ov && cur.valid;
+          best = st_round<OT>(best);  // the statistics describe the pooled map as it is stored
           if (st) {
-            p.out[(long long)cur.ns_ * p.out_ns + (long long)o * p.out_cs + cur.poff] = best;
+            SP<OT>(p.out).st1((long long)cur.ns_ * p.out_ns + (long long)o * p.out_cs + cur.poff, best);
             p.pool_idx[((long long)cur.ns_ * p.Cout + o) * PP + cur.poff] = (unsigned char)bi;
           }
           const float s1 = row16_sum(st ? best : 0.f);
@@ -305,7 +307,8 @@ __global__ __launch_bounds__(512, 2) void p1_fwd_k(const P1Fwd p) {
 static inline bool al8(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 7) == 0; }
 
 bool p1_fwd_supported(const P1Fwd& p) {
-  if (p.H < 2 || p.W < 2 || (p.W & 1) || (p.ns & 1) || (p.cs & 1) || !al8(p.S)) return false;
+  if (p.H < 2 || p.W < 2 || (p.W & 1) || (p.ns & 1) || (p.cs & 1)) return false;
+  if (reinterpret_cast<uintptr_t>(p.S) & (p.st == ST_BF16 ? 3 : 7)) return false;  // a pair of elements per load
   if (p.Cin < 8 || (p.Cin & 7) || p.Cout < 4 || (p.Cout & 3) || p.N < 1) return false;
   if ((long long)p.N * (p.H / 2) * (p.W / 2) + 16 >= (1ll << 31) || (long long)8 * p.cs + p.W >= (1ll << 31)) return false;
   return true;
@@ -319,13 +322,13 @@ void p1_fwd_plan(P1Fwd* p, int np) {
   p->bpg = (int)std::max(1ll, std::min((ntiles + 7) / 8, (long long)std::max(1, 256 / p->groups)));
 }
 
-template <int NP, int DT>
+template <int NP, int DT, int ST = ST_F32, int OT = ST_F32>
 static int p1_fwd_launch_t(const P1Fwd& p, hipStream_t s) {
   const int KS = (p.Cin + 31) / 32;
   const size_t lds = (size_t)p.mt * KS * NP * 1024 + (size_t)2 * KS * 32 * 4 + (size_t)8 * p.mt * 32 * 4 +
                      (size_t)p.mt * 16 * 4;
   if (lds > 160 * 1024) return -4;
-  auto kern = p1_fwd_k<NP, DT>;
+  auto kern = p1_fwd_k<NP, DT, ST, OT>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -340,6 +343,12 @@ static int p1_fwd_launch_t(const P1Fwd& p, hipStream_t s) {
 int p1_fwd_launch(const P1Fwd& p, int np, int dt, hipStream_t s) {
   if (!p1_fwd_supported(p) || p.mt < 1 || p.mt > 8 || p.groups < 1 || p.bpg < 1) return -4;
   if (p.mt * p.groups * 16 < p.Cout) return -4;
+  if (p.st == ST_BF16 || p.ot == ST_BF16) {  // bf16 storage on either side = plain bf16 operands
+    if (np != 1 || dt != D3_BF16) return -4;
+    if (p.st == ST_BF16 && p.ot == ST_BF16) return p1_fwd_launch_t<1, D3_BF16, ST_BF16, ST_BF16>(p, s);
+    if (p.st == ST_BF16) return p1_fwd_launch_t<1, D3_BF16, ST_BF16, ST_F32>(p, s);
+    return p1_fwd_launch_t<1, D3_BF16, ST_F32, ST_BF16>(p, s);
+  }
   if (dt == D3_BF16) {
     if (np == 1) return p1_fwd_launch_t<1, D3_BF16>(p, s);
     if (np == 2) return p1_fwd_launch_t<2, D3_BF16>(p, s);
@@ -361,7 +370,7 @@ int p1_fwd_launch(const P1Fwd& p, int np, int dt, hipStream_t s) {
 // DPP row sums into the wave's LDS slots), G (+)= gamma * gz.  Odd H: the last row has no window (its gz is zero); it is
 // covered by an extra window row whose second pixel row lies outside the image.
 // =============================================================================================
-template <int NP, int DT>
+template <int NP, int DT, int ST, int YT>
 __global__ __launch_bounds__(512, 2) void p1_dgrad_k(const P1Dgrad p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -401,7 +410,7 @@ __global__ __launch_bounds__(512, 2) void p1_dgrad_k(const P1Dgrad p) {
   const int tstride = p.bpg * 8;
 
   struct Tile {
-    const float* gbase;          // dYp at (sample, channel 0, window)
+    SP<YT> gbase;                // dYp at (sample, channel 0, window)
     const unsigned char* ibase;  // pool_idx, same
     long long pix;               // pixel offset of the window's first row inside the sample (S / G views)
     bool valid, win, row1;       // lane has a window slot / the window exists (pooled) / its second pixel row exists
@@ -417,25 +426,28 @@ __global__ __launch_bounds__(512, 2) void p1_dgrad_k(const P1Dgrad p) {
     t.win = t.valid && wy < PH;
     t.row1 = 2 * wy + 1 < p.H;
     const int poff = min(wy, PH - 1) * PW + wx;
-    t.gbase = p.dYp + (long long)ns_ * p.Cout * PP + poff;
+    t.gbase = SP<YT>(p.dYp) + ((long long)ns_ * p.Cout * PP + poff);
     t.ibase = p.pool_idx + (long long)ns_ * p.Cout * PP + poff;
     t.pix = (long long)ns_ * p.ns + (long long)(2 * wy) * p.W + 2 * wx;
     return t;
   };
 
-  float gv[8];
+  typename SRaw<YT>::r1 gvr[8];
   unsigned char iv[8];
   auto issue = [&](const Tile& t, int ks) __attribute__((always_inline)) {
     const long long off = (long long)min(ks * 32 + kb * 8, p.Cout - 8) * PP;  // Cout % 8 == 0; weights past Cout are zero
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      gv[e] = t.gbase[off + (long long)e * PP];
+      gvr[e] = t.gbase.raw1(off + (long long)e * PP);
       iv[e] = t.ibase[off + (long long)e * PP];
     }
   };
   uint4 bf[4][NP];
   auto convert = [&](bool win) __attribute__((always_inline)) {
     unsigned w[4][NP];
+    float gv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gv[e] = SRaw<YT>::w1(gvr[e]);
 #pragma unroll
     for (int j = 0; j < 4; ++j) split2<DT, NP>(win ? gv[2 * j] : 0.f, win ? gv[2 * j + 1] : 0.f, w[j]);
 #pragma unroll
@@ -497,8 +509,8 @@ __global__ __launch_bounds__(512, 2) void p1_dgrad_k(const P1Dgrad p) {
           cvr[r] = c < p.C && cur.valid;
           const long long off = cur.pix + (long long)min(c, p.C - 1) * p.cs;
           const long long off1 = cur.row1 ? off + p.W : off;
-          s0[r] = *reinterpret_cast<const float2*>(p.S + off);
-          s1[r] = *reinterpret_cast<const float2*>(p.S + off1);
+          s0[r] = SP<ST>(p.S).ld2(off);
+          s1[r] = SP<ST>(p.S).ld2(off1);
           g0[r] = *reinterpret_cast<const float2*>(p.G + off);
           g1[r] = *reinterpret_cast<const float2*>(p.G + off1);
         }
@@ -559,7 +571,8 @@ __global__ __launch_bounds__(512, 2) void p1_dgrad_k(const P1Dgrad p) {
 }
 
 bool p1_dgrad_supported(const P1Dgrad& p) {
-  if (p.H < 2 || p.W < 2 || (p.W & 1) || (p.ns & 1) || (p.cs & 1) || !al8(p.S) || !al8(p.G)) return false;
+  if (p.H < 2 || p.W < 2 || (p.W & 1) || (p.ns & 1) || (p.cs & 1) || !al8(p.G)) return false;
+  if (reinterpret_cast<uintptr_t>(p.S) & (p.st == ST_BF16 ? 3 : 7)) return false;
   if (p.C < 1 || p.Cout < 8 || (p.Cout & 7) || p.N < 1) return false;
   if ((long long)p.N * ((p.H + 1) / 2) * (p.W / 2) + 16 >= (1ll << 31)) return false;
   return true;
@@ -573,12 +586,12 @@ void p1_dgrad_plan(P1Dgrad* p, int np) {
   p->bpg = (int)std::max(1ll, std::min((ntiles + 7) / 8, (long long)std::max(1, 256 / p->groups)));
 }
 
-template <int NP, int DT>
+template <int NP, int DT, int ST = ST_F32, int YT = ST_F32>
 static int p1_dgrad_launch_t(const P1Dgrad& p, hipStream_t s) {
   const int KS = (p.Cout + 31) / 32;
   const size_t lds = (size_t)p.mt * KS * NP * 1024 + (size_t)p.mt * 16 * 8 * 4 + (size_t)8 * p.mt * 32 * 4;
   if (lds > 160 * 1024) return -4;
-  auto kern = p1_dgrad_k<NP, DT>;
+  auto kern = p1_dgrad_k<NP, DT, ST, YT>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -593,7 +606,14 @@ static int p1_dgrad_launch_t(const P1Dgrad& p, hipStream_t s) {
 int p1_dgrad_launch(const P1Dgrad& p, int np, int dt, hipStream_t s) {
   if (!p1_dgrad_supported(p) || p.mt < 1 || p.mt > 8 || p.groups < 1 || p.bpg < 1) return -4;
   if (p.mt * p.groups * 16 < p.C) return -4;
+  if ((p.st == ST_BF16 || p.yt == ST_BF16) && dt != D3_BF16) return -4;
   if (dt == D3_BF16) {
+    if (p.st == ST_BF16 || p.yt == ST_BF16) {  // bf16 storage = plain bf16 operands
+      if (np != 1) return -4;
+      if (p.st == ST_BF16 && p.yt == ST_BF16) return p1_dgrad_launch_t<1, D3_BF16, ST_BF16, ST_BF16>(p, s);
+      if (p.st == ST_BF16) return p1_dgrad_launch_t<1, D3_BF16, ST_BF16, ST_F32>(p, s);
+      return p1_dgrad_launch_t<1, D3_BF16, ST_F32, ST_BF16>(p, s);
+    }
     if (np == 1) return p1_dgrad_launch_t<1, D3_BF16>(p, s);
     if (np == 2) return p1_dgrad_launch_t<2, D3_BF16>(p, s);
     if (np == 3) return p1_dgrad_launch_t<3, D3_BF16>(p, s);
@@ -616,7 +636,7 @@ int p1_dgrad_launch(const P1Dgrad& p, int np, int dt, hipStream_t s) {
 // the whole range, partial[range][o][c] is reduced afterwards (fixed order).  Slabs never straddle samples; windows past
 // the end of a sample's window plane carry zero gradient.
 // =============================================================================================
-template <int NP, int DT, bool V4>
+template <int NP, int DT, bool V4, int ST, int YT>
 __global__ __launch_bounds__(256, 2) void p1_wgrad_k(const P1Wgrad p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -636,7 +656,7 @@ __global__ __launch_bounds__(256, 2) void p1_wgrad_k(const P1Wgrad p) {
   // B side: this wave's two N tiles
   int cch[2];
   float ba[2], bb[2];
-  const float* sb[2];
+  SP<ST> sb[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int c = (cb * 8 + 2 * wave + i) * 16 + n16;
@@ -644,7 +664,7 @@ __global__ __launch_bounds__(256, 2) void p1_wgrad_k(const P1Wgrad p) {
     const int cc = min(c, p.Cin - 1);
     ba[i] = c < p.Cin ? p.pa[cc] : 0.f;
     bb[i] = c < p.Cin ? p.pb[cc] : 0.f;
-    sb[i] = p.S + (long long)cc * p.cs;
+    sb[i] = SP<ST>(p.S) + (long long)cc * p.cs;
   }
   const bool wave_active = (cb * 8 + 2 * wave) * 16 < p.Cin;
 
@@ -669,7 +689,7 @@ __global__ __launch_bounds__(256, 2) void p1_wgrad_k(const P1Wgrad p) {
         for (int row = 0; row < 2; ++row)
 #pragma unroll
           for (int j2 = 0; j2 < 2; ++j2) {
-            const float4 v = *reinterpret_cast<const float4*>(sb[i] + off[j2] + row * p.W);
+            const float4 v = sb[i].ld4(off[j2] + row * p.W);
             raw[j2][i][0][row] = make_float2(v.x, v.y);
             raw[j2][i][1][row] = make_float2(v.z, v.w);
           }
@@ -683,8 +703,8 @@ __global__ __launch_bounds__(256, 2) void p1_wgrad_k(const P1Wgrad p) {
           const long long off = (long long)ns_ * p.ns + (long long)(2 * wy) * p.W + 2 * wx;
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
-            raw[j2][i][j][0] = *reinterpret_cast<const float2*>(sb[i] + off);
-            raw[j2][i][j][1] = *reinterpret_cast<const float2*>(sb[i] + off + p.W);
+            raw[j2][i][j][0] = sb[i].ld2(off);
+            raw[j2][i][j][1] = sb[i].ld2(off + p.W);
           }
         }
     }
@@ -724,7 +744,7 @@ __global__ __launch_bounds__(256, 2) void p1_wgrad_k(const P1Wgrad p) {
       const long long base = ((long long)ns_ * p.Cout + o) * PP;
       if constexpr (V4) {  // PP even: the window pair is 8-byte (values) / 2-byte (indices) aligned
         const int w = min(w0 + j2 * 8 + 2 * (l >> 4), PP - 2);
-        const float2 g2 = *reinterpret_cast<const float2*>(p.dYp + base + w);
+        const float2 g2 = SP<YT>(p.dYp).ld2(base + w);
         const uchar2 i2 = *reinterpret_cast<const uchar2*>(p.pool_idx + base + w);
         ag[q][0] = g2.x;
         ag[q][1] = g2.y;
@@ -734,7 +754,7 @@ __global__ __launch_bounds__(256, 2) void p1_wgrad_k(const P1Wgrad p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int w = min(w0 + j2 * 8 + 2 * (l >> 4) + j, PP - 1);
-          ag[q][j] = p.dYp[base + w];
+          ag[q][j] = SP<YT>(p.dYp).ld1(base + w);
           ai[q][j] = p.pool_idx[base + w];
         }
       }
@@ -830,7 +850,8 @@ __global__ __launch_bounds__(256, 2) void p1_wgrad_k(const P1Wgrad p) {
 }
 
 bool p1_wgrad_supported(const P1Wgrad& p) {
-  if (p.H < 2 || p.W < 2 || (p.W & 1) || (p.ns & 1) || (p.cs & 1) || !al8(p.S)) return false;
+  if (p.H < 2 || p.W < 2 || (p.W & 1) || (p.ns & 1) || (p.cs & 1)) return false;
+  if (reinterpret_cast<uintptr_t>(p.S) & (p.st == ST_BF16 ? 3 : 7)) return false;
   if (p.Cin < 1 || p.Cout < 1 || p.N < 1) return false;
   if ((long long)p.N * (p.H / 2) * (p.W / 2) + 16 >= (1ll << 31)) return false;
   return true;
@@ -849,10 +870,10 @@ void p1_wgrad_plan(P1Wgrad* p) {
   p->nranges = (int)((slabs + per - 1) / per);
 }
 
-template <int NP, int DT, bool V4>
+template <int NP, int DT, bool V4, int ST, int YT>
 static int p1_wgrad_launch_v(const P1Wgrad& p, hipStream_t s) {
   const size_t lds = (size_t)2 * 2 * 8 * NP * 1024;
-  auto kern = p1_wgrad_k<NP, DT, V4>;
+  auto kern = p1_wgrad_k<NP, DT, V4, ST, YT>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -864,19 +885,26 @@ static int p1_wgrad_launch_v(const P1Wgrad& p, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
-template <int NP, int DT>
+template <int NP, int DT, int ST = ST_F32, int YT = ST_F32>
 static int p1_wgrad_launch_t(const P1Wgrad& p, hipStream_t s) {
   const int PW = p.W / 2, PP = (p.H / 2) * PW;
   const bool v4 = (PW % 2) == 0 && (PP % 2) == 0 && PP >= 2 && (p.ns % 4) == 0 && (p.cs % 4) == 0 &&
-                  (reinterpret_cast<uintptr_t>(p.S) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.dYp) & 7) == 0 &&
+                  (reinterpret_cast<uintptr_t>(p.S) & (4 * st_bytes(ST) - 1)) == 0 &&
+                  (reinterpret_cast<uintptr_t>(p.dYp) & (2 * st_bytes(YT) - 1)) == 0 &&
                   (reinterpret_cast<uintptr_t>(p.pool_idx) & 1) == 0;
-  return v4 ? p1_wgrad_launch_v<NP, DT, true>(p, s) : p1_wgrad_launch_v<NP, DT, false>(p, s);
+  return v4 ? p1_wgrad_launch_v<NP, DT, true, ST, YT>(p, s) : p1_wgrad_launch_v<NP, DT, false, ST, YT>(p, s);
 }
 
 int p1_wgrad_launch(const P1Wgrad& p, int np, int dt, hipStream_t s) {
   if (!p1_wgrad_supported(p) || p.mo < 1 || p.mo > 8 || p.ogroups < 1 || p.cblocks < 1 || p.nranges < 1 || p.per < 1)
     return -4;
   if (p.mo * p.ogroups * 16 < p.Cout || p.cblocks * 128 < p.Cin) return -4;
+  if (p.st == ST_BF16 || p.yt == ST_BF16) {  // bf16 storage = plain bf16 operands
+    if (np != 1 || dt != D3_BF16) return -4;
+    if (p.st == ST_BF16 && p.yt == ST_BF16) return p1_wgrad_launch_t<1, D3_BF16, ST_BF16, ST_BF16>(p, s);
+    if (p.st == ST_BF16) return p1_wgrad_launch_t<1, D3_BF16, ST_BF16, ST_F32>(p, s);
+    return p1_wgrad_launch_t<1, D3_BF16, ST_F32, ST_BF16>(p, s);
+  }
   if (dt == D3_BF16) {
     if (np == 1) return p1_wgrad_launch_t<1, D3_BF16>(p, s);
     if (np == 2) return p1_wgrad_launch_t<2, D3_BF16>(p, s);

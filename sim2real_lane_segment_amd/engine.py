@@ -121,6 +121,7 @@ class Engine:
         self.step_seed = 0
         self.fwd_token = 0
         self.dense_arith = (0, "bf16", 0, "bf16")
+        self.storage = "f32"
         self.allocate(device)
         arith = DEFAULT_DENSE_ARITH if dense_arith is None else dense_arith
         if arith is not None:
@@ -202,6 +203,21 @@ class Engine:
         self.dense_arith = (int(fwd_parts), fwd_dtype, int(bwd_parts), bwd_dtype)
         self._ws = None
         self._ws_key = None
+
+    def set_storage(self, mode):
+        """'f32' (default) or 'bf16': element type of the activation stacks / finalised output gradients in HBM
+        (rln_set_storage, include/rln.h).  'bf16' switches the arithmetic to one-part bf16 operands."""
+        code = {"f32": 0, "fp32": 0, "bf16": 1, 0: 0, 1: 1}[mode]
+        _lib.check(self.L.rln_set_storage(self.ctx, code), "rln_set_storage")
+        self.storage = "bf16" if code else "f32"
+        if code:
+            self.dense_arith = (1, "bf16", 1, "bf16")
+        self._ws = None
+        self._ws_key = None
+
+    @property
+    def wgrad_parts(self):
+        return int(self.L.rln_get_wgrad_parts(self.ctx))
 
     def set_wgrad_parts(self, parts):
         """Operand parts of the dense weight-gradient GEMMs (rln_set_wgrad_parts; 0 = as the backward arithmetic)."""
