@@ -30,6 +30,7 @@ PEAK_16BIT_MFMA_TFLOPS = 2500.0  # dense bf16 / f16 MFMA peak (same guide; not t
 PEAK_HBM_GBS = 8000.0
 TRAIN_FLOPS_PER_IMAGE = 47_718_689_280  # 3 x 15,906,229,760
 PMC_SUMMARY = "r02_pmc_traffic.json"     # profiles/: FETCH_SIZE / WRITE_SIZE passes of this same command
+PMC_SUMMARY_BF16 = "r03_pmc_traffic_bf16.json"
 
 # kernel-name prefixes of each profiled class in the rocprofv3 --pmc summary
 CLASS_KERNELS = {
@@ -44,11 +45,11 @@ CLASS_KERNELS = {
 SPLIT_CLASSES = ("dense3_fwd", "dense3_wgrad", "dense3_dgrad_pull")
 
 
-def pmc_traffic(class_name):
+def pmc_traffic(class_name, summary=None):
     """HBM bytes per launch of a kernel class from the committed PMC pass (FETCH_SIZE/WRITE_SIZE collected in their
     own rocprofv3 --pmc runs of this same command and corrected as tools/pmc_traffic.py documents); None if the
     summary or the class mapping is absent.  Not collected live: counters need the profiler around the process."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", PMC_SUMMARY)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", summary or PMC_SUMMARY)
     pref = CLASS_KERNELS.get(class_name)
     if pref is None or not os.path.exists(path):
         return None
@@ -141,6 +142,73 @@ def cpu_baseline(batch=8, timed=5, budget_s=60.0):
     return out
 
 
+def roofline_of(prof, eng, instrumented_ms, images, elapsed, args):
+    """Roofline object of the dominant kernel class (largest summed event time among the classes with flops)."""
+    timed = [p for p in prof if p["launches"] > 0]
+    total_ms = sum(p["ms"] for p in timed)
+    dom = max((p for p in timed if p["flops"] > 0), key=lambda p: p["ms"])
+    fwd_parts, _, bwd_parts, _ = eng.dense_arith
+    parts = fwd_parts if dom["name"] == "dense3_fwd" else bwd_parts
+    products = {1: 1, 2: 3, 3: 6}.get(parts, 1) if dom["name"] in SPLIT_CLASSES else 1
+    if dom["name"] == "dense3_wgrad":
+        products = {1: 1, 2: 3, 3: 6}.get(eng.wgrad_parts, 1)  # rln_set_wgrad_parts
+    mfma_peak = PEAK_16BIT_MFMA_TFLOPS if dom["name"] in SPLIT_CLASSES else PEAK_F32_MFMA_TFLOPS
+    tfl = dom["flops"] / (dom["ms"] * 1e-3) / 1e12          # algorithmic flops (2 per multiply-add)
+    gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9           # algorithmic bytes (2 B per stack element with bf16 storage)
+    mfma_frac = tfl * products / mfma_peak                  # matrix-pipe work incl. the split products
+    hbm_frac = gbs / PEAK_HBM_GBS
+    # the binding roof of a class is the one its work sits closer to (DESIGN.md section 5)
+    if mfma_frac >= hbm_frac:
+        roof = {"bound": "mfma", "achieved": round(tfl * products, 3), "peak": mfma_peak, "unit": "TFLOP/s",
+                "frac": round(mfma_frac, 4)}
+    else:
+        roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(hbm_frac, 4)}
+    summary = PMC_SUMMARY_BF16 if eng.storage == "bf16" else PMC_SUMMARY
+    roof.update({
+        "kernel": dom["name"], "traffic": pmc_traffic(dom["name"], summary),
+        "traffic_unit": f"HBM bytes per launch (rocprofv3 --pmc pass, profiles/{summary})",
+        "alg_bytes_per_launch": round(dom["bytes"] / dom["launches"]), "launches": dom["launches"],
+        "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
+        "share_of_kernel_time": round(dom["ms"] / total_ms, 4),
+        "instrumented_ms_per_step": round(instrumented_ms, 3),
+        "alg_tflops": round(tfl, 3), "alg_GBps": round(gbs, 1),
+        "mfma_products_per_mac": products, "frac_of_mfma_peak": round(mfma_frac, 4),
+        "frac_of_hbm_peak": round(hbm_frac, 4)})
+    if images is not None and (args.height, args.width) == (120, 160):
+        roof["whole_step_tflops"] = round(TRAIN_FLOPS_PER_IMAGE * images / elapsed / 1e12, 3)
+        roof["whole_step_frac_of_f32_mfma_peak"] = round(TRAIN_FLOPS_PER_IMAGE * images / elapsed / 1e12
+                                                         / PEAK_F32_MFMA_TFLOPS, 4)
+    return roof
+
+
+def inference_bench(dev, build, h=480, w=640):
+    """BASELINE.json configs[3]: eval-mode forward of FCDenseNet67 at the demo size (makeDemoVideo.py:36, test.py:93-94
+    call model.forward on .eval() modules), frames resident in HBM, batch 1 (the demo script's) and 16."""
+    from sim2real_lane_segment_amd.synthetic import make_batch
+    out = {"workload": f"FCDenseNet67 num_cls=4 eval forward (BatchNorm running statistics, no Dropout2d) -> probabilities, "
+                       f"3x{h}x{w} synthetic frames resident in HBM", "unit": "frames/sec"}
+    x16, _ = make_batch(16, h, w, seed=7, device=dev, work_device=dev)
+    for storage in ("f32", "bf16"):
+        model, eng = build(storage)
+        model.eval()
+        for n in (1, 16):
+            x = x16[:n].contiguous()
+            for _ in range(3):
+                eng.forward(x, training=False)
+            torch.cuda.synchronize()
+            reps = 20 if n == 1 else 5
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                eng.forward(x, training=False)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+            out[f"{storage}_n{n}"] = {"fps": round(n / dt, 1), "ms_per_batch": round(1000.0 * dt, 3)}
+        del model, eng
+        torch.cuda.empty_cache()
+    return out
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: starts N fresh worker processes (one per device, RCCL
     rendezvous on 127.0.0.1) BEFORE this process touches the GPU, relays rank 0's JSON line and fails loudly if
@@ -189,10 +257,20 @@ def main():
                          "path training_step -> loss.backward() -> optimizer.step() (what Lightning drives)")
     ap.add_argument("--no-module-api", action="store_true", help="skip the secondary module-API timing")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
-                    help="f32 (default): fp32-parity arithmetic (split 16-bit MFMA operands, DESIGN.md 4.1); bf16: plain "
-                         "one-part bf16 MFMA operands in the dense 3x3 kernels (storage and accumulation stay fp32) -- the "
-                         "throughput mode of BASELINE.json configs[1]; its mask agreement is measured in "
-                         "tests/test_gpu_dense3.py")
+                    help="f32 (default): fp32 activation stacks, split 16-bit MFMA operands at fp32-parity error "
+                         "(DESIGN.md 4.1); bf16: the bf16-storage mode of BASELINE.json configs[1] -- activation stacks and "
+                         "finalised output gradients of the levels that carry the traffic are bf16 in HBM, plain bf16 MFMA "
+                         "operands, fp32 accumulation / statistics / gradient stacks / parameters (rln_set_storage; its "
+                         "mask agreement and gradient error are measured in tests/test_gpu_bf16_storage.py)")
+    ap.add_argument("--augment", dest="augment", action="store_true", default=True,
+                    help="(default) the README baseline command's --augment: uint8 frames resident in HBM go through the "
+                         "device transform (HueSaturationValue, RandomSizedCrop, MotionBlur / GaussNoise, Normalize) inside "
+                         "every timed step")
+    ap.add_argument("--no-augment", dest="augment", action="store_false",
+                    help="feed pre-normalised fp32 frames instead (rounds 1-2 did)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the other storage mode's line and the inference object")
+    ap.add_argument("--no-inference", action="store_true", help="skip the 480x640 inference object")
     ap.add_argument("--fwd-arith", default=None, help="dense 3x3 forward arithmetic: fp32 | bf16x1..3 | f16x1..2")
     ap.add_argument("--bwd-arith", default=None, help="dense 3x3 backward arithmetic: fp32 | bf16x1..3 | f16x1..2")
     args = ap.parse_args()
@@ -224,30 +302,29 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
 
+    from sim2real_lane_segment_amd import _lib
+    from sim2real_lane_segment_amd.dataManagement.myTransforms import MyTransform
     from sim2real_lane_segment_amd.synthetic import make_batch
     from sim2real_lane_segment_amd.trainer import TrainStepper
     from sim2real_lane_segment_amd.trainingModules.SimpleTrain import SimpleTrainModule
 
-    torch.manual_seed(42)
-    model = SimpleTrainModule(lr=1e-3, lrRatio=1e3, decay=1e-4, num_cls=4).to(dev)  # random init, FCDenseNet67
-    model.train()
-    eng = model._rln_sync()
-    if args.dtype == "bf16" and not (args.fwd_arith or args.bwd_arith):
-        args.fwd_arith = args.bwd_arith = "bf16x1"
-    if args.fwd_arith or args.bwd_arith:
-        def parse(a):
-            if a in (None, "fp32"):
-                return 0, "bf16"
-            t, n = a.split("x")
-            return int(n), t
-        fp, ft = parse(args.fwd_arith)
-        bp, bt = parse(args.bwd_arith)
-        eng.set_dense_arith(fp, ft, bp, bt)
-    stepper = TrainStepper(eng, lr=1e-3, weight_decay=1e-4, n_buckets=args.buckets, force_collectives=args.force_dist)
-    stepper.broadcast_parameters()
-    if dist.is_initialized() and dist.get_world_size() != world:
-        print(f"[bench] RCCL world size {dist.get_world_size()} != WORLD_SIZE {world}", file=sys.stderr)
-        sys.exit(5)
+    B = args.batch
+    FH, FW = 4 * args.height, 4 * args.width
+    if args.augment:
+        # BASELINE.json configs[1] / README.md:139 "--augment": full-size uint8 frames + uint8 label masks resident in HBM
+        # -> MyTransform(augment=True) on device (rln_augment_u8: HSV jitter, random-sized crop, blur / noise, normalise)
+        # INSIDE every timed step; the per-image random parameters are drawn on the host as albumentations draws them
+        pool = [make_batch(B, args.height, args.width, seed=42, first_index=(rank * 4 + i) * B, device=dev,
+                           frames_u8=True, work_device=dev) for i in range(2)]
+        aug = MyTransform(width=args.width, height=args.height, augment=True, device=dev, seed=1234 + rank)
+    else:
+        pool = [make_batch(B, args.height, args.width, seed=42, first_index=(rank * 4 + i) * B, device=dev)
+                for i in range(2)]
+        aug = None
+
+    def batch_of(i):
+        fx, fy = pool[i % len(pool)]
+        return aug(fx, fy) if aug is not None else (fx, fy)
 
     class ModuleStepper:
         """The reference-shaped path: what Lightning runs per batch (SimpleTrain.py:11-30)."""
@@ -267,66 +344,103 @@ def main():
             self.opt.step()
             return loss.detach().reshape(1)
 
+    def timed(stepper, steps, warmup, barrier=False):
+        for i in range(warmup):
+            out = stepper.step(*batch_of(i))
+        torch.cuda.synchronize()
+        if barrier and world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            out = stepper.step(*batch_of(i))
+        torch.cuda.synchronize()
+        if barrier and world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        return time.perf_counter() - t0, out
+
+    def build(storage, fwd_arith=None, bwd_arith=None):
+        torch.manual_seed(42)
+        model = SimpleTrainModule(lr=1e-3, lrRatio=1e3, decay=1e-4, num_cls=4).to(dev)  # random init, FCDenseNet67
+        model.train()
+        eng = model._rln_sync()
+        if storage == "bf16":
+            eng.set_storage("bf16")
+        if fwd_arith or bwd_arith:
+            def parse(a):
+                if a in (None, "fp32"):
+                    return 0, "bf16"
+                t, n = a.split("x")
+                return int(n), t
+            fp, ft = parse(fwd_arith)
+            bp, bt = parse(bwd_arith)
+            eng.set_dense_arith(fp, ft, bp, bt)
+        return model, eng
+
+    def profile_pass(eng, stepper, steps):
+        """The same steps again with HIP events around every kernel class (on the launch stream) -> roofline.  The ~600
+        event pairs per step cost a few % of wall time, so they stay out of the region `value` is taken from."""
+        _lib.check(_lib.lib().rln_profile_enable(eng.ctx, 1))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(steps):
+            stepper.step(*batch_of(i))
+        torch.cuda.synchronize()
+        ms = 1000.0 * (time.perf_counter() - t1) / steps
+        prof = read_profile(eng)
+        _lib.check(_lib.lib().rln_profile_enable(eng.ctx, 0))
+        return prof, ms
+
+    if args.dtype == "bf16" and (args.fwd_arith or args.bwd_arith):
+        print("[bench] --dtype bf16 fixes the arithmetic to one-part bf16 operands", file=sys.stderr)
+        sys.exit(2)
+    model, eng = build(args.dtype, args.fwd_arith, args.bwd_arith)
+    stepper = TrainStepper(eng, lr=1e-3, weight_decay=1e-4, n_buckets=args.buckets, force_collectives=args.force_dist)
+    stepper.broadcast_parameters()
+    if dist.is_initialized() and dist.get_world_size() != world:
+        print(f"[bench] RCCL world size {dist.get_world_size()} != WORLD_SIZE {world}", file=sys.stderr)
+        sys.exit(5)
     engine_stepper = stepper
     if args.api == "module":
         stepper = ModuleStepper(model)
 
-    B = args.batch
-    pool = [make_batch(B, args.height, args.width, seed=42, first_index=(rank * 4 + i) * B, device=dev)
-            for i in range(2)]
-    for i in range(args.warmup):
-        x, y = pool[i % len(pool)]
-        out = stepper.step(x, y)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    from sim2real_lane_segment_amd import _lib
-    # ---- timed region: EXACTLY K steps, no instrumentation in the stream ----
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        x, y = pool[i % len(pool)]
-        out = stepper.step(x, y)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    # ---- timed region: W warm-up steps, then EXACTLY K steps between barrier + synchronize, no instrumentation ----
+    elapsed, out = timed(stepper, args.steps, args.warmup, barrier=True)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss = float(out[0])
-    # ---- the same K steps again with HIP events around every kernel class (launch stream) -> roofline.  The
-    # ~600 event pairs per step cost a few % of wall time, so they stay out of the region `value` is taken from;
-    # the per-class kernel durations they measure are the quantity the roofline needs. ----
+
     prof = None
     instrumented_ms = None
     module_api = None
-    if args.api == "engine" and world == 1 and not args.no_module_api:
-        ms = ModuleStepper(model)
-        for i in range(2):
-            ms.step(*pool[i % len(pool)])
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(args.steps):
-            ms.step(*pool[i % len(pool)])
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t1
+    secondary = {}
+    single = world == 1 and not args.force_dist
+    if args.api == "engine" and single and not args.no_module_api:
+        dt, _ = timed(ModuleStepper(model), args.steps, 2)
         module_api = {"value": round(B * args.steps / dt, 2), "unit": "images/sec",
                       "ms_per_step": round(1000.0 * dt / args.steps, 3),
                       "path": "SimpleTrainModule.training_step -> loss.backward() -> FusedAdamW.step()"}
     if not args.no_profile:
-        _lib.check(_lib.lib().rln_profile_enable(eng.ctx, 1))
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(args.steps):
-            x, y = pool[i % len(pool)]
-            stepper.step(x, y)
-        torch.cuda.synchronize()
-        instrumented_ms = 1000.0 * (time.perf_counter() - t1) / args.steps
-        prof = read_profile(eng)
-        _lib.check(_lib.lib().rln_profile_enable(eng.ctx, 0))
+        prof, instrumented_ms = profile_pass(eng, stepper, args.steps)
+    if single and not args.no_secondary and args.api == "engine" and not (args.fwd_arith or args.bwd_arith):
+        # the other storage mode, same workload and region, as an object of the same line
+        other = "bf16" if args.dtype == "f32" else "f32"
+        model2, eng2 = build(other)
+        st2 = TrainStepper(eng2, lr=1e-3, weight_decay=1e-4)
+        dt2, out2 = timed(st2, args.steps, args.warmup)
+        sec = {"value": round(B * args.steps / dt2, 2), "unit": "images/sec", "dtype": other,
+               "ms_per_step": round(1000.0 * dt2 / args.steps, 3), "final_loss": round(float(out2[0]), 5)}
+        if not args.no_profile:
+            prof2, ims2 = profile_pass(eng2, st2, args.steps)
+            sec["roofline"] = roofline_of(prof2, eng2, ims2, None, None, args)
+        secondary["storage_" + other] = sec
+        del st2, model2, eng2
+        torch.cuda.empty_cache()
+        if not args.no_inference:
+            secondary["inference_480x640"] = inference_bench(dev, build)
 
     if rank == 0:
         images = world * B * args.steps
@@ -350,55 +464,31 @@ def main():
                                    f"random-init weights, Dropout2d+BatchNorm in train mode",
                        "global_batch": world * B, "parallelism": f"dp{world}", "final_loss": round(loss, 5),
                        "api": args.api,
-                       "dense_arith": "fwd %sx%d / bwd %sx%d split-operand MFMA (0 parts = exact fp32 MFMA), fp32 storage "
-                                      "and accumulation" % (eng.dense_arith[1], eng.dense_arith[0], eng.dense_arith[3],
-                                                            eng.dense_arith[2])},
+                       "input": (f"uint8 {FH}x{FW} frames + label masks resident in HBM -> MyTransform(augment=True) on device "
+                                 "(rln_augment_u8) inside every timed step (README.md:139 --augment)") if args.augment
+                       else "pre-normalised fp32 frames resident in HBM (no augmentation in the step)",
+                       # the exact arithmetic of this line (dtype names the storage / accumulate class only)
+                       "storage": ("bf16 activation stacks + finalised output gradients on the levels with rows >= 40 px, "
+                                   "fp32 deep levels / gradient stacks / statistics / parameters") if eng.storage == "bf16"
+                       else "fp32 everywhere",
+                       "dense_arith": "fwd %sx%d / data-gradient %sx%d / dense weight-gradient %sx%d (where N*H*W >= 2400, "
+                                      "else as the data gradient) split-operand 16-bit MFMA products, fp32 accumulation "
+                                      "(0 parts = exact fp32 MFMA)" % (eng.dense_arith[1], eng.dense_arith[0],
+                                                                      eng.dense_arith[3], eng.dense_arith[2],
+                                                                      eng.dense_arith[3], eng.wgrad_parts)},
         }
         if module_api is not None:
             result["module_api"] = module_api
         if prof is not None:
-            timed = [p for p in prof if p["launches"] > 0]
-            total_ms = sum(p["ms"] for p in timed)
-            dom = max((p for p in timed if p["flops"] > 0), key=lambda p: p["ms"])
-            fwd_parts, _, bwd_parts, _ = eng.dense_arith
-            parts = fwd_parts if dom["name"] == "dense3_fwd" else bwd_parts
-            products = {1: 1, 2: 3, 3: 6}.get(parts, 1) if dom["name"] in SPLIT_CLASSES else 1
-            if dom["name"] == "dense3_wgrad" and parts == 2:
-                products = 1  # one-part operands in the dense weight gradient (rln_set_wgrad_parts)
-            mfma_peak = PEAK_16BIT_MFMA_TFLOPS if dom["name"] in SPLIT_CLASSES else PEAK_F32_MFMA_TFLOPS
-            tfl = dom["flops"] / (dom["ms"] * 1e-3) / 1e12          # algorithmic flops (2 per multiply-add)
-            gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9           # algorithmic bytes
-            mfma_frac = tfl * products / mfma_peak                  # matrix-pipe work incl. the split products
-            hbm_frac = gbs / PEAK_HBM_GBS
-            # the binding roof of a class is the one its work sits closer to
-            if mfma_frac >= hbm_frac:
-                roof = {"bound": "mfma", "achieved": round(tfl * products, 3), "peak": mfma_peak, "unit": "TFLOP/s",
-                        "frac": round(mfma_frac, 4)}
-            else:
-                roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": round(hbm_frac, 4)}
-            roof.update({
-                "kernel": dom["name"], "traffic": pmc_traffic(dom["name"]),
-                "traffic_unit": f"HBM bytes per launch (rocprofv3 --pmc pass, profiles/{PMC_SUMMARY})",
-                "alg_bytes_per_launch": round(dom["bytes"] / dom["launches"]), "launches": dom["launches"],
-                "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
-                "share_of_kernel_time": round(dom["ms"] / total_ms, 4),
-                "instrumented_ms_per_step": round(instrumented_ms, 3),
-                "alg_tflops": round(tfl, 3), "alg_GBps": round(gbs, 1),
-                "mfma_products_per_mac": products, "frac_of_mfma_peak": round(mfma_frac, 4),
-                "frac_of_hbm_peak": round(hbm_frac, 4),
-                "whole_step_tflops": round(TRAIN_FLOPS_PER_IMAGE * images / elapsed / 1e12, 3)
-                if (args.height, args.width) == (120, 160) else None,
-                "whole_step_frac_of_f32_mfma_peak": round(TRAIN_FLOPS_PER_IMAGE * images / elapsed / 1e12
-                                                          / PEAK_F32_MFMA_TFLOPS, 4)
-                if (args.height, args.width) == (120, 160) else None})
-            result["roofline"] = roof
+            result["roofline"] = roofline_of(prof, eng, instrumented_ms, images, elapsed, args)
+            timed_classes = [q for q in prof if q["launches"] > 0]
             result["kernel_classes"] = [
-                {"name": p["name"], "ms_per_step": round(p["ms"] / args.steps, 4),
-                 "launches_per_step": p["launches"] // args.steps,
-                 "tflops": round(p["flops"] / (p["ms"] * 1e-3) / 1e12, 2) if p["flops"] and p["ms"] else None,
-                 "alg_GBps": round(p["bytes"] / (p["ms"] * 1e-3) / 1e9, 1) if p["bytes"] and p["ms"] else None}
-                for p in sorted(timed, key=lambda p: -p["ms"])]
+                {"name": q["name"], "ms_per_step": round(q["ms"] / args.steps, 4),
+                 "launches_per_step": q["launches"] // args.steps,
+                 "tflops": round(q["flops"] / (q["ms"] * 1e-3) / 1e12, 2) if q["flops"] and q["ms"] else None,
+                 "alg_GBps": round(q["bytes"] / (q["ms"] * 1e-3) / 1e9, 1) if q["bytes"] and q["ms"] else None}
+                for q in sorted(timed_classes, key=lambda q: -q["ms"])]
+        result.update(secondary)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
         sys.stdout.flush()

@@ -41,7 +41,13 @@ static int fail(int code, const char* fmt, ...) {
 #define RLN_TRY(expr)                                                                   \
   do {                                                                                  \
     int _e = (expr);                                                                    \
-    if (_e != 0) return fail(_e, "%s failed with %d (%s:%d)", #expr, _e, __FILE__, __LINE__); \
+    if (_e != 0) {                                                                      \
+      char _inner[256];                                                                 \
+      snprintf(_inner, sizeof(_inner), "%s", g_err);                                    \
+      g_err[0] = 0;                                                                     \
+      return fail(_e, "%s failed with %d (%s:%d)%s%s", #expr, _e, __FILE__, __LINE__,   \
+                  _inner[0] ? " <- " : "", _inner);                                     \
+    }                                                                                   \
   } while (0)
 
 namespace {
@@ -1157,7 +1163,7 @@ HeadParams head_params(rln_ctx* c) {
 // ---------------------------------------------------------------------------------------------
 
 int finalize_grad_range(rln_ctx* c, int level, int ch_off, int C, const float* nscale, long long* rows,
-                        hipStream_t s, float* dst = nullptr) {
+                        hipStream_t s, float* dst = nullptr, int yt = -1) {
   const Level& lv = c->levels[level];
   GradFinParams g;
   memset(&g, 0, sizeof(g));
@@ -1180,7 +1186,8 @@ int finalize_grad_range(rln_ctx* c, int level, int ch_off, int C, const float* n
   g.Hd = lv.H;
   g.Wd = lv.W;
   g.st = lv.st;
-  ProfScope ps(c, PC_GRADFIN, 0, (4.0 + 2.0 * st_bytes(lv.st)) * c->N * C * plane, s);
+  g.yt = yt < 0 ? lv.st : yt;  // the finalised gradients share the level's storage type unless the consumer asks otherwise
+  ProfScope ps(c, PC_GRADFIN, 0, (4.0 + st_bytes(lv.st) + st_bytes(g.yt)) * c->N * C * plane, s);
   RLN_TRY(grad_finalize(g, c->N, rows, s));
   return 0;
 }
@@ -1494,7 +1501,7 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
           f.bias_partial = c->bpartial;
           f.Hd = dl.H;
           f.Wd = dl.W;
-          f.st = dl.st;
+          f.st = f.yt = dl.st;
           ProfScope ps(c, PC_GRADFIN, 0, (4.0 + 2.0 * st_bytes(dl.st)) * N * o.cout * dplane, s);
           RLN_TRY(grad_finalize(f, N, &rows, s));
         }
@@ -1638,7 +1645,31 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
     const Level& sl = c->levels[o.src_level];
     const Level& dl = c->levels[o.dst_level];
     const size_t splane = (size_t)sl.H * sl.W, dplane = (size_t)dl.H * dl.W;
-    RLN_TRY(finalize_grad_range(c, o.dst_level, 0, o.cout, nullptr, &rows, s));
+    // dU takes the destination level's storage type when the split-operand weight-gradient kernel covers the geometry;
+    // at the boundary to the deep fp32 levels (input rows of < 8 pixels in octets) it is finalised as fp32 for the
+    // exact-fp32 weight-gradient kernel
+    int yt = dl.st;
+    if (yt != ST_F32) {
+      C3Wgrad probe;
+      memset(&probe, 0, sizeof(probe));
+      probe.X = sl.sp(o.in_off);
+      probe.ns = (long long)sl.C * splane;
+      probe.cs = (int)splane;
+      probe.H = sl.H;
+      probe.W = sl.W;
+      probe.Cin = o.cin;
+      probe.N = N;
+      probe.dU = c->dY;
+      probe.Cout = o.cout;
+      probe.Ho = dl.H;
+      probe.Wo = dl.W;
+      probe.st = sl.st;
+      probe.yt = yt;
+      if (!c3_wgrad_supported(probe)) yt = ST_F32;
+      if (yt == ST_F32 && sl.st != ST_F32)
+        return fail(RLN_ERR_UNSUPPORTED, "op %zu: transition up not covered by the bf16-storage weight-gradient kernel", k);
+    }
+    RLN_TRY(finalize_grad_range(c, o.dst_level, 0, o.cout, nullptr, &rows, s, nullptr, yt));
     // (the bias rows are reduced together with the weight slabs below)
     IgemmParams p;
     memset(&p, 0, sizeof(p));
@@ -1685,7 +1716,7 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
       q.W = sl.W;
       q.C = o.cin;
       q.N = N;
-      q.yt = dl.st;
+      q.yt = yt;
       if (c3_dgrad_supported(q)) {
         c3_dgrad_plan(&q);
         const double flops = 2.0 * o.cin * o.cout * 9.0 * splane * N;
@@ -1695,7 +1726,7 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
         dgrad_done = true;
       }
     }
-    if (!dgrad_done && dl.st != ST_F32)
+    if (!dgrad_done && yt != ST_F32)
       return fail(RLN_ERR_UNSUPPORTED, "op %zu: transition up not covered by the bf16-storage data-gradient kernel", k);
     if (!dgrad_done) {
       const double flops = 2.0 * o.cin * o.cout * 9.0 * splane * N;
@@ -1719,7 +1750,7 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
       g.Wo = dl.W;
       g.partial = c->wpartial;
       g.st = sl.st;
-      g.yt = dl.st;
+      g.yt = yt;
       if (c3_wgrad_supported(g)) {
         c3_wgrad_plan(&g);
         RLN_TRY(wg_begin(c, s, &ws));
@@ -1747,7 +1778,7 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
         return 0;
       }
     }
-    if (sl.st != ST_F32 || dl.st != ST_F32)
+    if (sl.st != ST_F32 || yt != ST_F32)
       return fail(RLN_ERR_UNSUPPORTED, "op %zu: transition up not covered by the bf16-storage weight-gradient kernel", k);
     RLN_TRY(reduce_rows(c->bpartial, rows, o.cout, c->grads + o.conv.b, s));
     WgradParams w;
@@ -1870,7 +1901,7 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
 #endif
         {
           const double wflops = 2.0 * o.cout * o.cin * 9.0 * plane * N;
-          const double wbytes = 4.0 * N * ((double)o.cout + o.cin) * plane;
+          const double wbytes = (double)st_bytes(lv.st) * N * ((double)o.cout + o.cin) * plane;
           ProfScope ps(c, PC_D3_WGRAD, wflops, wbytes, s);
           RLN_TRY(d3_wgrad_launch(g, wgrad_parts(c, (long long)N * lv.H * lv.W), c->d3_bwd_dt, s));
         }
@@ -1931,7 +1962,8 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
       p.out_vec = ((lv.W % 4) == 0 && aligned16(p.out) && aligned16(p.S)) ? 1 : 0;
       {
         const double flops = 2.0 * Jn * o.cout * 9.0 * plane * N;
-        const double bytes = 4.0 * N * plane * ((double)o.cout + 2.0 * Jn + (double)(p.acc_hi - p.acc_lo));
+        const double eb = (double)st_bytes(lv.st);  // dY and S in the level's storage type, G in fp32
+        const double bytes = (double)N * plane * (eb * o.cout + (eb + 4.0) * Jn + 4.0 * (p.acc_hi - p.acc_lo));
         ProfScope ps(c, PC_DENSE_DGRAD, flops, bytes, s);
         if (o.cout <= 16) {
           RLN_TRY(dgrad_loop_launch(tile, p, N, s));
@@ -1989,7 +2021,8 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
     {
       double flops = 0.0;
       for (int i = 0; i < nl; ++i) flops += 2.0 * C0 * first.cout * 9.0 * plane * N;
-      const double bytes = 4.0 * N * plane * ((double)nl * first.cout + 2.0 * C0 + (double)(q.acc_hi - q.acc_lo));
+      const double eb = (double)st_bytes(lv.st);  // dY and S in the level's storage type, G in fp32
+      const double bytes = (double)N * plane * (eb * nl * first.cout + (eb + 4.0) * C0 + 4.0 * (q.acc_hi - q.acc_lo));
       ProfScope ps(c, PC_D3_PULL, flops, bytes, s);
       RLN_TRY(d3_pull_launch(q, c->d3_bwd_np, c->d3_bwd_dt, s));
     }

@@ -41,7 +41,7 @@ struct GradFinParams {
   // pool-backward variant: dst is the pre-pool map (Hd x Wd), S/G are the pooled maps (H x W)
   const unsigned char* pool_idx;  // [N][C][H][W] or null
   int Hd, Wd;
-  int st;  // storage element type of S and of dst (storage.h); G is fp32
+  int st, yt;  // storage element types of S and of dst (storage.h); G is fp32
 };
 // returns number of bias_partial rows through *rows
 int grad_finalize(const GradFinParams& p, int N, long long* rows, hipStream_t s);

@@ -192,7 +192,7 @@ int bn_bwd_finalize(const float* partial, long long nblk, int J, const float* ga
 // gradient finalisation:  d/dx = invstd * (G - S1/M - xhat * S2/M)  [* dropout scale]
 // =============================================================================================
 
-template <int ST>  // storage element type of S and of dst (the level's activations and its finalised gradients)
+template <int ST, int YT>  // storage element types of S (the level's activations) and of dst (its finalised gradients)
 __global__ __launch_bounds__(256) void grad_finalize_k(const GradFinParams p) {
   const int c = blockIdx.y, n = blockIdx.z;
   const int tid = threadIdx.x;
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void grad_finalize_k(const GradFinParams p) {
   const SP<ST> Sp = SP<ST>(p.S) + ((long long)n * p.ns + (long long)c * plane);
   const float* Gp = p.G + (long long)n * p.ns + (long long)c * plane;
   const long long dplane = (long long)p.Hd * p.Wd;
-  const SP<ST> dp = SP<ST>(p.dst) + ((long long)n * p.C + c) * dplane;
+  const SP<YT> dp = SP<YT>(p.dst) + ((long long)n * p.C + c) * dplane;
   float bsum = 0.f;
   const long long e0 = (long long)blockIdx.x * 1024;
   if (p.pool_idx == nullptr) {
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void grad_finalize_k(const GradFinParams p) {
       const long long e = e0 + i * 256 + tid;
       if (e < dplane) {
         const float xh = (Sp.ld1(e) - mean) * is;
-        const float v = st_round<ST>(sc * is * (Gp[e] - k1 - xh * k2));  // the bias gradient sums what is stored
+        const float v = st_round<YT>(sc * is * (Gp[e] - k1 - xh * k2));  // the bias gradient sums what is stored
         dp.st1(e, v);
         bsum += v;
       }
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void grad_finalize_k(const GradFinParams p) {
           const long long q = (long long)py * p.W + px;
           if ((int)ip[q] == (((yd & 1) << 1) | (xd & 1))) {
             const float xh = (Sp.ld1(q) - mean) * is;
-            v = st_round<ST>(sc * is * (Gp[q] - k1 - xh * k2));
+            v = st_round<YT>(sc * is * (Gp[q] - k1 - xh * k2));
           }
         }
         dp.st1(e, v);
@@ -259,10 +259,15 @@ long long grad_finalize_rows(int N, int Hd, int Wd) {
 int grad_finalize(const GradFinParams& p, int N, long long* rows, hipStream_t s) {
   const long long nbx = ((long long)p.Hd * p.Wd + 1023) / 1024;
   if (rows) *rows = nbx * N;
-  if (p.st == ST_BF16)
-    hipLaunchKernelGGL(grad_finalize_k<ST_BF16>, dim3((unsigned)nbx, (unsigned)p.C, (unsigned)N), dim3(256), 0, s, p);
+  const dim3 grid((unsigned)nbx, (unsigned)p.C, (unsigned)N);
+  if (p.st == ST_BF16 && p.yt == ST_BF16)
+    hipLaunchKernelGGL((grad_finalize_k<ST_BF16, ST_BF16>), grid, dim3(256), 0, s, p);
+  else if (p.st == ST_BF16)
+    hipLaunchKernelGGL((grad_finalize_k<ST_BF16, ST_F32>), grid, dim3(256), 0, s, p);
+  else if (p.yt == ST_BF16)
+    return -4;
   else
-    hipLaunchKernelGGL(grad_finalize_k<ST_F32>, dim3((unsigned)nbx, (unsigned)p.C, (unsigned)N), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((grad_finalize_k<ST_F32, ST_F32>), grid, dim3(256), 0, s, p);
   RLN_LAUNCH_CHECK();
 }
 

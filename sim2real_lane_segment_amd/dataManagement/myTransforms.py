@@ -95,7 +95,10 @@ class MyTransform:
                 or (params[:, 3] + params[:, 5] > hs).any() or (params[:, 4] + params[:, 6] > ws).any():
             raise ValueError("crop box outside the frame")
         self.last_params = params
-        pd = torch.from_numpy(params).to(self.device)
+        # pinned staging + asynchronous copy: a pageable copy would block the host until the stream has drained, i.e.
+        # serialise the host's launch work with the previous step's kernels (torch's host allocator keeps the pinned
+        # block alive until the copy has run)
+        pd = torch.from_numpy(params).pin_memory().to(self.device, non_blocking=True)
         out = torch.empty((n, 3, self.height, self.width), dtype=torch.float32, device=self.device)
         tmp = torch.empty((n, self.height, self.width, 3), dtype=torch.uint8, device=self.device)
         y_out = torch.empty((n, self.height, self.width), dtype=torch.int64, device=self.device) if have_label else None

@@ -18,13 +18,20 @@ MEAN = (0.485, 0.456, 0.406)
 STD = (0.229, 0.224, 0.225)
 
 
-def make_batch(n, h=120, w=160, seed=42, first_index=0, device="cpu", domains=None):
+def make_batch(n, h=120, w=160, seed=42, first_index=0, device="cpu", domains=None, frames_u8=False, work_device="cpu"):
     """Returns (x float32 [n,3,h,w], y int64 [n,h,w]); sample i depends only on seed + first_index + i (and on
-    domains[i] in {0, 1} when given)."""
+    domains[i] in {0, 1} when given).  frames_u8=True returns the full-size frames instead, as the reference's datasets
+    hand them to MyTransform (myDatasets.py:45-61): (uint8 [n,4h,4w,3] in stored BGR order, uint8 labels [n,4h,4w]).
+    work_device: where the per-pixel drawing runs (the random numbers always come from the CPU generator, so a sample
+    is the same wherever it is drawn, up to the last-bit rounding of the vignette)."""
     xs, ys = [], []
     fh, fw = 4 * h, 4 * w
-    yy = torch.arange(fh, dtype=torch.float32).view(fh, 1)
-    xx = torch.arange(fw, dtype=torch.float32).view(1, fw)
+    wd = torch.device(work_device)
+    yy = torch.arange(fh, dtype=torch.float32, device=wd).view(fh, 1)
+    xx = torch.arange(fw, dtype=torch.float32, device=wd).view(1, fw)
+
+    def T(vals):
+        return torch.tensor(vals, device=wd).view(3, 1, 1)
     for i in range(n):
         g = torch.Generator().manual_seed(seed + first_index + i)
         r = torch.rand(8, generator=g)
@@ -34,21 +41,21 @@ def make_batch(n, h=120, w=160, seed=42, first_index=0, device="cpu", domains=No
         half = (0.04 + 0.46 * t) * fw                               # road half-width grows toward the camera
         below = yy > horizon
         on_road = below & ((xx - cx).abs() < half)
-        img = torch.empty(3, fh, fw)
+        img = torch.empty(3, fh, fw, device=wd)
         real = domains is not None and int(domains[i]) == 1
         if real:  # indoor wall / floor instead of sky / grass, darker road with a coarse texture
-            sky = torch.tensor([150.0, 150.0, 155.0]).view(3, 1, 1) * (0.7 + 0.3 * float(r[2]))
-            grass = torch.tensor([105.0, 110.0, 120.0]).view(3, 1, 1) * (0.7 + 0.3 * float(r[3]))
-            tex = torch.nn.functional.interpolate(torch.rand(1, 1, fh // 8, fw // 8, generator=g), size=(fh, fw),
+            sky = T([150.0, 150.0, 155.0]) * (0.7 + 0.3 * float(r[2]))
+            grass = T([105.0, 110.0, 120.0]) * (0.7 + 0.3 * float(r[3]))
+            tex = torch.nn.functional.interpolate(torch.rand(1, 1, fh // 8, fw // 8, generator=g).to(wd), size=(fh, fw),
                                                   mode="nearest")[0] * 30.0 - 15.0
             road = (55.0 + tex).expand(3, fh, fw)
         else:
-            sky = torch.tensor([200.0, 170.0, 120.0]).view(3, 1, 1) * (0.8 + 0.2 * float(r[2]))
-            grass = torch.tensor([60.0, 130.0, 70.0]).view(3, 1, 1) * (0.8 + 0.2 * float(r[3]))
-            road = torch.full((3, fh, fw), 90.0)
+            sky = T([200.0, 170.0, 120.0]) * (0.8 + 0.2 * float(r[2]))
+            grass = T([60.0, 130.0, 70.0]) * (0.8 + 0.2 * float(r[3]))
+            road = torch.full((3, fh, fw), 90.0, device=wd)
         img[:] = torch.where(below.expand(3, fh, fw), grass.expand(3, fh, fw), sky.expand(3, fh, fw))
         img = torch.where(on_road.expand(3, fh, fw), road, img)
-        lab = torch.zeros(fh, fw, dtype=torch.int64)
+        lab = torch.zeros(fh, fw, dtype=torch.int64, device=wd)
         right = on_road & (xx > cx)
         left = on_road & (xx <= cx)
         lab[right] = 1
@@ -57,29 +64,33 @@ def make_batch(n, h=120, w=160, seed=42, first_index=0, device="cpu", domains=No
         edge = below & (((xx - cx).abs() - half).abs() < stripe_w)           # white side lines
         centre = below & ((xx - cx).abs() < stripe_w) & (((yy / (fh / 12.0)).floor() % 2) == 0)  # dashed yellow
         img = torch.where(edge.expand(3, fh, fw), torch.full_like(img, 190.0 if real else 235.0), img)
-        yellow = (torch.tensor([60.0, 170.0, 185.0]) if real else torch.tensor([40.0, 210.0, 230.0])).view(3, 1, 1) \
-            .expand(3, fh, fw)
+        yellow = (T([60.0, 170.0, 185.0]) if real else T([40.0, 210.0, 230.0])).expand(3, fh, fw)
         img = torch.where(centre.expand(3, fh, fw), yellow, img)
         if (first_index + i) % 8 != 7:  # obstacle (a box on the road), absent in every 8th sample
             oy = horizon + (fh - horizon) * (0.3 + 0.5 * float(r[4]))
             ox = cx + (float(r[5]) - 0.5) * fw * 0.3
             osz = fh * (0.05 + 0.08 * float(r[6]))
             box = ((yy - oy).abs() < osz) & ((xx - ox).abs() < osz * 0.8)
-            img = torch.where(box.expand(3, fh, fw), torch.tensor([30.0, 40.0, 200.0]).view(3, 1, 1).expand(3, fh, fw),
-                              img)
+            img = torch.where(box.expand(3, fh, fw), T([30.0, 40.0, 200.0]).expand(3, fh, fw), img)
             lab[box] = 3
         if real:  # vignetting + 3x the sensor noise
             vig = 1.0 - 0.35 * (((yy - fh / 2) / (fh / 2)) ** 2 + ((xx - fw / 2) / (fw / 2)) ** 2) / 2
             img = img * vig
-            img = (img + (torch.rand(3, fh, fw, generator=g) * 48 - 24)).clamp(0, 255).round()
+            img = (img + (torch.rand(3, fh, fw, generator=g).to(wd) * 48 - 24)).clamp(0, 255).round()
         else:
-            img = (img + (torch.rand(3, fh, fw, generator=g) * 16 - 8)).clamp(0, 255).round()
+            img = (img + (torch.rand(3, fh, fw, generator=g).to(wd) * 16 - 8)).clamp(0, 255).round()
+        if frames_u8:
+            xs.append(img.permute(1, 2, 0).to(torch.uint8))
+            ys.append(lab.to(torch.uint8))
+            continue
         small = torch.nn.functional.avg_pool2d(img.unsqueeze(0), 4).squeeze(0)   # area average of 4x4 blocks
         lab_small = lab[2::4, 2::4].contiguous()                                 # nearest for labels
-        mean = torch.tensor(MEAN).view(3, 1, 1)
-        std = torch.tensor(STD).view(3, 1, 1)
+        mean = T(list(MEAN))
+        std = T(list(STD))
         xs.append((small / 255.0 - mean) / std)
         ys.append(lab_small)
+    if frames_u8:
+        return torch.stack(xs).contiguous().to(device), torch.stack(ys).contiguous().to(device)
     x = torch.stack(xs).float().contiguous()
     y = torch.stack(ys).contiguous()
     return x.to(device), y.to(device)
