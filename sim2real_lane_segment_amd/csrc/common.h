@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <cstdlib>
 
 namespace rln {
@@ -16,6 +17,24 @@ constexpr const char* rln_env(const char*) { return nullptr; }
 #endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// One-time-per-DEVICE latch for per-kernel function attributes (hipFuncAttributeMaxDynamicSharedMemorySize is a
+// per-device property: a process that drives a second device must set it there too).  first() is true once per device;
+// undo() re-arms the current device after a failed attempt.
+struct DevOnce {
+  std::atomic<unsigned long long> mask{0};
+  static unsigned long long bit() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return 0;
+    return 1ull << d;
+  }
+  bool first() {
+    const unsigned long long b = bit();
+    if (b == 0) return true;  // unknown device index: set the attribute every time
+    return !(mask.fetch_or(b) & b);
+  }
+  void undo() { mask.fetch_and(~bit()); }
+};
 
 // v_mfma_f32_16x16x4_f32: D[i][j] += sum_k A[i][k] * B[k][j], exact fp32 (fmaf chain).
 // Lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; it receives

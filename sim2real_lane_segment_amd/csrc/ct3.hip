@@ -54,7 +54,8 @@ __global__ __launch_bounds__(256) void c3_pack_k(const float* __restrict__ param
     const int k = ks * 32 + kb * 8 + e;
     float val = 0.f;
     if (!backward) {  // row = o, k = c
-      if (row < q.cout && k < q.cin) val = w[((long long)k * q.cout + row) * 9 + tap];
+      if (row < q.cout && k < q.cin)
+        val = sat16<DT>(w[((long long)k * q.cout + row) * 9 + tap] * w_prescale<DT>());  // split16.h: f16 range handling
     } else {  // row = c, k = o
       if (row < q.cin && k < q.cout) val = w[((long long)row * q.cout + k) * 9 + tap];
     }
@@ -186,8 +187,11 @@ __global__ __launch_bounds__(512, 2) void c3_fwd_k(const C3Fwd p) {
     unsigned a[4][NP], u[4][NP];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      split2<DT, NP>(c.v_own ? SRaw<XT>::w1(qo[w][2 * j]) : 0.f, c.v_own ? SRaw<XT>::w1(qo[w][2 * j + 1]) : 0.f, a[j]);
-      split2<DT, NP>(c.v_up ? SRaw<XT>::w1(qu[w][2 * j]) : 0.f, c.v_up ? SRaw<XT>::w1(qu[w][2 * j + 1]) : 0.f, u[j]);
+      // raw (un-normalised) block output: saturate into the part type's range before the split (split16.h)
+      split2<DT, NP>(c.v_own ? sat16<DT>(SRaw<XT>::w1(qo[w][2 * j])) : 0.f,
+                     c.v_own ? sat16<DT>(SRaw<XT>::w1(qo[w][2 * j + 1])) : 0.f, a[j]);
+      split2<DT, NP>(c.v_up ? sat16<DT>(SRaw<XT>::w1(qu[w][2 * j])) : 0.f,
+                     c.v_up ? sat16<DT>(SRaw<XT>::w1(qu[w][2 * j + 1])) : 0.f, u[j]);
     }
 #pragma unroll
     for (int pt = 0; pt < NP; ++pt) {
@@ -276,7 +280,8 @@ __global__ __launch_bounds__(512, 2) void c3_fwd_k(const C3Fwd p) {
             const bool ov = o < p.Cout;
             float v[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = st_round<OT>(acc[m][w][q][r] + bia[r]);  // statistics of the stored tensor
+            for (int q = 0; q < 4; ++q)  // (rounded first: statistics of the stored tensor)
+              v[q] = st_round<OT>(fmaf(acc[m][w][q][r], w_unscale<DT>(), bia[r]));
             const SP<OT> dst = c.outp + (long long)o * p.out_cs;
             const bool m00 = ov && r0v && x0v, m01 = ov && r0v && x1v, m10 = ov && r1v && x0v, m11 = ov && r1v && x1v;
             if (vec2) {  // Wo even: a block column pair is all-in or all-out
@@ -348,12 +353,15 @@ static int c3_fwd_launch_t(const C3Fwd& p, hipStream_t s) {
   const size_t lds = (size_t)p.mt * KS * 9 * NP * 1024 + (size_t)p.mt * 16 * 4 + (size_t)8 * p.mt * 32 * 4;
   if (lds > 160 * 1024) return -4;
   auto kern = c3_fwd_k<NP, DT, ST, OT>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+  static DevOnce attr_once;
+  if (attr_once.first()) {
+    const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
-    (void)hipGetLastError();
-    attr_done = true;
+    if (attr_err != hipSuccess) {  // refused: report it here instead of an opaque launch failure later
+      (void)hipGetLastError();
+      attr_once.undo();
+      return (int)attr_err;
+    }
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(p.groups * p.bpg)), dim3(512), lds, s, p);
   return (int)hipGetLastError();
@@ -576,12 +584,15 @@ static int c3_dgrad_launch_t(const C3Dgrad& p, hipStream_t s) {
   const size_t lds = (size_t)2 * p.mt * 3 * NP * 1024;
   if (lds > 160 * 1024) return -4;
   auto kern = c3_dgrad_k<NP, DT, YT>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+  static DevOnce attr_once;
+  if (attr_once.first()) {
+    const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
-    (void)hipGetLastError();
-    attr_done = true;
+    if (attr_err != hipSuccess) {  // refused: report it here instead of an opaque launch failure later
+      (void)hipGetLastError();
+      attr_once.undo();
+      return (int)attr_err;
+    }
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(p.groups * p.bpg)), dim3(512), lds, s, p);
   return (int)hipGetLastError();

@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256) void d3_pack_k(const float* __restrict__ param
         // past the layer's input range; channels an earlier chunk already covered get zero weights
         const int cb = min(grp * 16, max(q.cin - 16, 0));
         const int ch = cb + kk;
-        if (n < q.cout && ch < q.cin && ch >= grp * 16) val = w[((long long)n * q.cin + ch) * 9 + tap];
+        if (n < q.cout && ch < q.cin && ch >= grp * 16)
+          val = sat16<DT>(w[((long long)n * q.cin + ch) * 9 + tap] * w_prescale<DT>());  // split16.h: f16 range handling
       } else {
         const int c = grp * 16 + n;
         if (kk < q.cout && c < q.cin) val = w[((long long)kk * q.cin + c) * 9 + (8 - tap)];
@@ -237,8 +238,8 @@ __global__ __launch_bounds__(768, 3) void d3_fwd_k(const D3Fwd p) {
       if (h_ok) {
         const int c0 = cb + 2 * h_cp;
         unsigned parts[NP];
-        split2<DT, NP>(fmaxf(fmaf(abtab[c0], SRaw<ST>::w1(R.h[0]), abtab[Cpad + c0]), 0.f),
-                       fmaxf(fmaf(abtab[c0 + 1], SRaw<ST>::w1(R.h[1]), abtab[Cpad + c0 + 1]), 0.f), parts);
+        split2<DT, NP>(relu16<DT>(fmaf(abtab[c0], SRaw<ST>::w1(R.h[0]), abtab[Cpad + c0])),
+                       relu16<DT>(fmaf(abtab[c0 + 1], SRaw<ST>::w1(R.h[1]), abtab[Cpad + c0 + 1])), parts);
 #pragma unroll
         for (int pt = 0; pt < NP; ++pt) *reinterpret_cast<unsigned*>(buf + pt * PLANE + h_lds) = parts[pt];
       }
@@ -257,8 +258,8 @@ __global__ __launch_bounds__(768, 3) void d3_fwd_k(const D3Fwd p) {
             const float4 u0 = SRaw<ST>::w4(R.s[2 * k]), u1 = SRaw<ST>::w4(R.s[2 * k + 1]);
             const float x0 = px == 0 ? u0.x : px == 1 ? u0.y : px == 2 ? u0.z : u0.w;
             const float x1 = px == 0 ? u1.x : px == 1 ? u1.y : px == 2 ? u1.z : u1.w;
-            split2<DT, NP>(fmaxf(fmaf(av[2 * k], x0, bv[2 * k]), 0.f),
-                           fmaxf(fmaf(av[2 * k + 1], x1, bv[2 * k + 1]), 0.f), parts[k]);
+            split2<DT, NP>(relu16<DT>(fmaf(av[2 * k], x0, bv[2 * k])),
+                           relu16<DT>(fmaf(av[2 * k + 1], x1, bv[2 * k + 1])), parts[k]);
           }
 #pragma unroll
           for (int pt = 0; pt < NP; ++pt)
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(768, 3) void d3_fwd_k(const D3Fwd p) {
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        v[r] = st_round<ST>((acc[m][r] + bias) * sc);  // the statistics describe the tensor as it is stored
+        v[r] = st_round<ST>(fmaf(acc[m][r], w_unscale<DT>(), bias) * sc);  // statistics of the tensor as it is stored
         if (ok) {
           s1 += v[r];
           s2 += v[r] * v[r];
@@ -448,12 +449,15 @@ static int d3_fwd_launch_t(const D3Fwd& p, int N, hipStream_t s) {
   const int Cpad = ((p.Cin + 15) / 16) * 16;
   const size_t lds = 2 * ((size_t)NP * rows * P * 32 + (size_t)5 * NP * 1024) + (size_t)2 * Cpad * 4 + 4 * 16 * 2 * 4;
   auto kern = d3_fwd_k<MPW, NR, NP, DT, ST>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+  static DevOnce attr_once;
+  if (attr_once.first()) {
+    const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
-    (void)hipGetLastError();
-    attr_done = true;
+    if (attr_err != hipSuccess) {  // refused: report it here instead of an opaque launch failure later
+      (void)hipGetLastError();
+      attr_once.undo();
+      return (int)attr_err;
+    }
   }
   if (lds > 160 * 1024) return -4;
   dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)std::max(1, p.ksplit), (unsigned)N);
@@ -840,12 +844,15 @@ static int d3_wgrad_launch_t(const D3Wgrad& p, hipStream_t s) {
   const size_t lds = (size_t)2 * NP * rows * P * 32 + (size_t)2 * NP * p.th * p.tw * 32 + 128;
   if (lds > 160 * 1024 || lds < 4 * 9 * 64 * 16) return -4;
   auto kern = d3_wgrad_k<NP, DT, ST>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+  static DevOnce attr_once;
+  if (attr_once.first()) {
+    const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
-    (void)hipGetLastError();
-    attr_done = true;
+    if (attr_err != hipSuccess) {  // refused: report it here instead of an opaque launch failure later
+      (void)hipGetLastError();
+      attr_once.undo();
+      return (int)attr_err;
+    }
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(p.nchunks * p.nranges)), dim3(768), lds, s, p);
   return (int)hipGetLastError();
@@ -1219,12 +1226,15 @@ static int d3_pull_launch_t(const D3Pull& p, hipStream_t s) {
   const size_t lds = d3_pull_lds(p, NP);
   if (lds > 160 * 1024) return -4;
   auto kern = d3_pull_k<NP, DT, ST>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+  static DevOnce attr_once;
+  if (attr_once.first()) {
+    const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
-    (void)hipGetLastError();
-    attr_done = true;
+    if (attr_err != hipSuccess) {  // refused: report it here instead of an opaque launch failure later
+      (void)hipGetLastError();
+      attr_once.undo();
+      return (int)attr_err;
+    }
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)d3_pull_blocks(p)), dim3(512), lds, s, p);
   return (int)hipGetLastError();

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256, 2) void f3_fwd_k(const F3Fwd p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int k = 8 * (l >> 4) + j;
-      v[j] = (o < p.Cout && k < K) ? p.w[(long long)o * K + k] : 0.f;
+      v[j] = (o < p.Cout && k < K) ? sat16<DT>(p.w[(long long)o * K + k] * w_prescale<DT>()) : 0.f;  // split16.h
     }
     unsigned parts[4][NP];
 #pragma unroll
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void f3_fwd_k(const F3Fwd p) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const bool ok = rv && (unsigned)(x0 + t + kdx[j]) < (unsigned)p.W;
-        v[t][j] = ok ? xb[koff[j] + t] : 0.f;
+        v[t][j] = ok ? sat16<DT>(xb[koff[j] + t]) : 0.f;  // raw input: saturate into the part type's range
       }
     }
     uint4 bf[4][NP];
@@ -107,8 +107,10 @@ __global__ __launch_bounds__(256, 2) void f3_fwd_k(const F3Fwd p) {
           const int o = m * 16 + kb4 + r;
           const bool st = pv && o < p.Cout;
           // (rounded to the storage type first: the statistics describe the tensor as it is stored)
-          const float4 ov = make_float4(st_round<OT>(acc[0][r] + bia[r]), st_round<OT>(acc[1][r] + bia[r]),
-                                        st_round<OT>(acc[2][r] + bia[r]), st_round<OT>(acc[3][r] + bia[r]));
+          const float4 ov = make_float4(st_round<OT>(fmaf(acc[0][r], w_unscale<DT>(), bia[r])),
+                                        st_round<OT>(fmaf(acc[1][r], w_unscale<DT>(), bia[r])),
+                                        st_round<OT>(fmaf(acc[2][r], w_unscale<DT>(), bia[r])),
+                                        st_round<OT>(fmaf(acc[3][r], w_unscale<DT>(), bia[r])));
           if (st) SP<OT>(p.out).st4((long long)ns_ * p.out_ns + (long long)o * p.out_cs + rem, ov.x, ov.y, ov.z, ov.w);
           float s1 = st ? (ov.x + ov.y) + (ov.z + ov.w) : 0.f;
           float s2 = st ? (ov.x * ov.x + ov.y * ov.y) + (ov.z * ov.z + ov.w * ov.w) : 0.f;

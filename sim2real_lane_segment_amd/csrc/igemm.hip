@@ -704,14 +704,17 @@ template <int KS, int NT, int PRO, int EPI, int TH, int TW, int CLS, bool V4>
 static int launch_v(const IgemmParams& p, int N, hipStream_t stream) {
   using C = IgCfg<KS, NT, PRO, EPI, TH, TW, V4>;
   if (C::AB_FLOATS > 0 && p.K > C::AB_MAX) return -4;
-  static bool attr_done = false;
+  static DevOnce attr_once;
   auto kern = igemm_k<KS, NT, PRO, EPI, TH, TW, CLS, V4>;
   if ((p.ncls > 1) != (CLS == 1)) return -1;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+  if (attr_once.first()) {
+    const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               C::LDS_BYTES);
-    (void)hipGetLastError();
-    attr_done = true;
+    if (attr_err != hipSuccess) {  // refused: report it here instead of an opaque launch failure later
+      (void)hipGetLastError();
+      attr_once.undo();
+      return (int)attr_err;
+    }
     if (rln_env("RLN_DEBUG_OCC")) {
       int nb = -1;
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 256, C::LDS_BYTES);
@@ -1109,13 +1112,16 @@ template <int TH, int TW, bool VEC, int ST = ST_F32>
 static int dgrad_loop_launch_t(const IgemmParams& p, int N, hipStream_t stream) {
   using C = IgCfg<3, 1, PRO_RAW, EPI_DGRAD, TH, TW>;
   const int LDS = (C::IN_FLOATS + 2 * C::W_FLOATS + 4 * (((p.J + 15) >> 4) * 16) * 2) * 4;
-  static bool attr_done = false;
+  static DevOnce attr_once;
   auto kern = dgrad_loop_k<TH, TW, VEC, ST>;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+  if (attr_once.first()) {
+    const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               96 * 1024);
-    (void)hipGetLastError();
-    attr_done = true;
+    if (attr_err != hipSuccess) {  // refused: report it here instead of an opaque launch failure later
+      (void)hipGetLastError();
+      attr_once.undo();
+      return (int)attr_err;
+    }
     if (rln_env("RLN_DEBUG_OCC")) {
       int nb = -1;
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 256, LDS);
@@ -1666,13 +1672,16 @@ __global__ __launch_bounds__(256, (NCH_ == 64 ? 2 : (NCH_ == 32 ? 3 : 4))) void 
 template <int TH, int TW, int NCH_>
 static int wlaunch_q(const WgradParams& p, hipStream_t stream) {
   using C = WgqCfg<TH, TW, NCH_>;
-  static bool attr_done = false;
+  static DevOnce attr_once;
   auto kern = wgrad_dense_q_k<TH, TW, NCH_>;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+  if (attr_once.first()) {
+    const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               C::LDS_BYTES);
-    (void)hipGetLastError();
-    attr_done = true;
+    if (attr_err != hipSuccess) {  // refused: report it here instead of an opaque launch failure later
+      (void)hipGetLastError();
+      attr_once.undo();
+      return (int)attr_err;
+    }
     if (rln_env("RLN_DEBUG_OCC")) {
       int nb = -1;
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 256, C::LDS_BYTES);
@@ -1687,13 +1696,16 @@ static int wlaunch_q(const WgradParams& p, hipStream_t stream) {
 template <int KS, int MT, int PRO, bool SHIFT_A, int TH, int TW>
 static int wlaunch_t(const WgradParams& p, hipStream_t stream) {
   using C = WgCfg<KS, MT, PRO, SHIFT_A, TH, TW>;
-  static bool attr_done = false;
+  static DevOnce attr_once;
   auto kern = wgrad_k<KS, MT, PRO, SHIFT_A, TH, TW>;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+  if (attr_once.first()) {
+    const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               C::LDS_BYTES);
-    (void)hipGetLastError();
-    attr_done = true;
+    if (attr_err != hipSuccess) {  // refused: report it here instead of an opaque launch failure later
+      (void)hipGetLastError();
+      attr_once.undo();
+      return (int)attr_err;
+    }
     if (rln_env("RLN_DEBUG_OCC")) {
       int nb = -1;
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 256, C::LDS_BYTES);

@@ -985,16 +985,23 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
       d3_fwd_pick_tile(q.H, q.W, c->d3_fwd_np, &q.th, &q.tw, &q.rg);
       q.tiles_y = (q.H + q.th - 1) / q.th;
       q.tiles_x = (q.W + q.tw - 1) / q.tw;
+      int e3;
       {
         const double flops = 2.0 * o.cin * o.cout * 9.0 * q.H * q.W * N;
         const double bytes = (double)st_bytes(dl.st) * N * ((double)o.cin + o.cout) * q.H * q.W;
         ProfScope ps(c, PC_D3_FWD, flops, bytes, s);
-        RLN_TRY(d3_fwd_launch(q, N, c->d3_fwd_np, c->d3_fwd_dt, s));
+        e3 = d3_fwd_launch(q, N, c->d3_fwd_np, c->d3_fwd_dt, s);
       }
-      if (training)
-        RLN_TRY(finalize_stats(c, o.dst_level, o.out_off, o.cout, (long long)N * q.tiles_x * q.tiles_y, s,
-                               (long long)k));
-      return 0;
+      // RLN_ERR_UNSUPPORTED from the launcher (tile / LDS budget of an unusual geometry) falls through to the exact-fp32
+      // family below, like a geometry d3_fwd_supported() rejects; nothing was launched in that case
+      if (e3 != 0 && (e3 != RLN_ERR_UNSUPPORTED || dl.st != ST_F32))
+        return fail(e3, "d3_fwd_launch failed with %d (op %zu)", e3, k);
+      if (e3 == 0) {
+        if (training)
+          RLN_TRY(finalize_stats(c, o.dst_level, o.out_off, o.cout, (long long)N * q.tiles_x * q.tiles_y, s,
+                                 (long long)k));
+        return 0;
+      }
     }
   }
   if (o.type == OP_FIRST && c->d3_fwd_np > 0) {  // split-operand 16-bit MFMA kernel (fc3.h)

@@ -985,12 +985,15 @@ int head_backward_fused(const HeadBwdParams& q, int N, float* wpartial, long lon
   };
 #define RLN_HEAD_FUSED(NCV, STV)                                                                                    \
   {                                                                                                                 \
-    static bool attr = false;                                                                                       \
-    if (!attr) {                                                                                                    \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head_bwd_fused_k<NCV, STV>),                          \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);                            \
-      (void)hipGetLastError();                                                                                      \
-      attr = true;                                                                                                  \
+    static DevOnce attr_once;                                                                                       \
+    if (attr_once.first()) {                                                                                        \
+      const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(head_bwd_fused_k<NCV, STV>),    \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);     \
+      if (attr_err != hipSuccess) {                                                                                 \
+        (void)hipGetLastError();                                                                                    \
+        attr_once.undo();                                                                                           \
+        return (int)attr_err;                                                                                       \
+      }                                                                                                             \
     }                                                                                                               \
     hipLaunchKernelGGL((head_bwd_fused_k<NCV, STV>), grid, dim3(256), lds(NCV), s, q, wpartial);                    \
   }

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void p1_pack_k(const float* __restrict__ param
     const int k = ks * 32 + kb * 8 + e;
     float val = 0.f;
     if (!backward) {
-      if (row < q.cout && k < q.cin) val = w[(long long)row * q.cin + k];
+      if (row < q.cout && k < q.cin) val = sat16<DT>(w[(long long)row * q.cin + k] * w_prescale<DT>());  // split16.h
     } else {
       if (row < q.cin && k < q.cout) val = w[(long long)k * q.cin + row];
     }
@@ -166,10 +166,10 @@ __global__ __launch_bounds__(512, 2) void p1_fwd_k(const P1Fwd p) {
     for (int e = 0; e < 8; ++e) {
       const float2 r0 = dbg_const ? make_float2(0.5f, -0.25f) : SRaw<ST>::w2(q0[e]);
       const float2 r1 = dbg_const ? make_float2(0.5f, -0.25f) : SRaw<ST>::w2(q1[e]);
-      z[0][e] = fmaxf(fmaf(av[e], r0.x, bv[e]), 0.f);
-      z[1][e] = fmaxf(fmaf(av[e], r0.y, bv[e]), 0.f);
-      z[2][e] = fmaxf(fmaf(av[e], r1.x, bv[e]), 0.f);
-      z[3][e] = fmaxf(fmaf(av[e], r1.y, bv[e]), 0.f);
+      z[0][e] = relu16<DT>(fmaf(av[e], r0.x, bv[e]));
+      z[1][e] = relu16<DT>(fmaf(av[e], r0.y, bv[e]));
+      z[2][e] = relu16<DT>(fmaf(av[e], r1.x, bv[e]));
+      z[3][e] = relu16<DT>(fmaf(av[e], r1.y, bv[e]));
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -259,11 +259,11 @@ __global__ __launch_bounds__(512, 2) void p1_fwd_k(const P1Fwd p) {
           const bool ov = o < p.Cout;
           const float bias = bia[r];
           const float sc = sca[r];
-          float best = (acc[m][0][r] + bias) * sc;
+          float best = fmaf(acc[m][0][r], w_unscale<DT>(), bias) * sc;
           int bi = 0;
 #pragma unroll
           for (int t = 1; t < 4; ++t) {
-            const float v = (acc[m][t][r] + bias) * sc;
+            const float v = fmaf(acc[m][t][r], w_unscale<DT>(), bias) * sc;
             if (v > best) {
               best = v;
               bi = t;
@@ -329,12 +329,15 @@ static int p1_fwd_launch_t(const P1Fwd& p, hipStream_t s) {
                      (size_t)p.mt * 16 * 4;
   if (lds > 160 * 1024) return -4;
   auto kern = p1_fwd_k<NP, DT, ST, OT>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+  static DevOnce attr_once;
+  if (attr_once.first()) {
+    const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
-    (void)hipGetLastError();
-    attr_done = true;
+    if (attr_err != hipSuccess) {  // refused: report it here instead of an opaque launch failure later
+      (void)hipGetLastError();
+      attr_once.undo();
+      return (int)attr_err;
+    }
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(p.groups * p.bpg)), dim3(512), lds, s, p);
   return (int)hipGetLastError();
@@ -592,12 +595,15 @@ static int p1_dgrad_launch_t(const P1Dgrad& p, hipStream_t s) {
   const size_t lds = (size_t)p.mt * KS * NP * 1024 + (size_t)p.mt * 16 * 8 * 4 + (size_t)8 * p.mt * 32 * 4;
   if (lds > 160 * 1024) return -4;
   auto kern = p1_dgrad_k<NP, DT, ST, YT>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+  static DevOnce attr_once;
+  if (attr_once.first()) {
+    const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
-    (void)hipGetLastError();
-    attr_done = true;
+    if (attr_err != hipSuccess) {  // refused: report it here instead of an opaque launch failure later
+      (void)hipGetLastError();
+      attr_once.undo();
+      return (int)attr_err;
+    }
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(p.groups * p.bpg)), dim3(512), lds, s, p);
   return (int)hipGetLastError();
@@ -874,12 +880,15 @@ template <int NP, int DT, bool V4, int ST, int YT>
 static int p1_wgrad_launch_v(const P1Wgrad& p, hipStream_t s) {
   const size_t lds = (size_t)2 * 2 * 8 * NP * 1024;
   auto kern = p1_wgrad_k<NP, DT, V4, ST, YT>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+  static DevOnce attr_once;
+  if (attr_once.first()) {
+    const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
-    (void)hipGetLastError();
-    attr_done = true;
+    if (attr_err != hipSuccess) {  // refused: report it here instead of an opaque launch failure later
+      (void)hipGetLastError();
+      attr_once.undo();
+      return (int)attr_err;
+    }
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(p.nranges * p.ogroups * p.cblocks)), dim3(256), lds, s, p);
   return (int)hipGetLastError();

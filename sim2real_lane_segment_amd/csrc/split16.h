@@ -46,6 +46,34 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned (&out)[NP]) 
   }
 }
 
+// ---- f16 range handling (forward kernels; bf16 parts have fp32's exponent range and need none of this) -------------
+// f16 parts cover |x| <= 65504 and lose relative precision below 2^-3 (the low part of a two-part split becomes
+// subnormal: absolute error <= 2^-25 instead of relative 2^-22).  Three rules keep the f16x2 forward in the accuracy
+// class of the fp32 MFMA chain and free of inf / NaN:
+//   * activations behind BatchNorm + ReLU are clamped to [0, 65504] by the v_med3_f32 that replaces the ReLU's v_max
+//     (same instruction count); raw inputs (first convolution, TransitionUp) are clamped to +-65504 before the split;
+//     values beyond that range saturate instead of turning into inf - inf = NaN;
+//   * forward-orientation weights are packed times 2^8 (Kaiming-scale weights ~1e-2 would put their low part into the
+//     subnormal range: 2^-17 instead of 2^-22 relative) and saturate at |w| = 255.9; the kernels' epilogues multiply
+//     the fp32 accumulator by 2^-8, which is exact;
+//   * small activations keep an ABSOLUTE error <= 2^-25 per element, far below the fp32 rounding of the O(1) sums
+//     they enter.
+constexpr float kF16Max = 65504.f;
+template <int DT>
+__device__ __forceinline__ constexpr float w_prescale() { return DT == D3_F16 ? 256.f : 1.f; }
+template <int DT>
+__device__ __forceinline__ constexpr float w_unscale() { return DT == D3_F16 ? (1.f / 256.f) : 1.f; }
+template <int DT>
+__device__ __forceinline__ float relu16(float v) {  // ReLU, saturating at the part type's largest finite value
+  if constexpr (DT == D3_F16) return __builtin_amdgcn_fmed3f(v, 0.f, kF16Max);
+  else return fmaxf(v, 0.f);
+}
+template <int DT>
+__device__ __forceinline__ float sat16(float v) {
+  if constexpr (DT == D3_F16) return __builtin_amdgcn_fmed3f(v, -kF16Max, kF16Max);
+  else return v;
+}
+
 template <int DT>
 __device__ __forceinline__ f32x4 mfma32(const uint4& a, const uint4& b, f32x4 c) {
   if constexpr (DT == D3_BF16) {

@@ -28,6 +28,10 @@ class MMETrainingModule(TrainingBase):
 
     def training_step(self, batch, batch_idx, optimizer_idx=0, drop_scales=None, seed=None):
         x_labelled, x_unlabelled, labels, _ = batch
+        if optimizer_idx == 0:
+            x_unlabelled, _ = self._rln_prepare_batch(x_unlabelled, None, train=True)
+        else:
+            x_labelled, labels = self._rln_prepare_batch(x_labelled, labels, train=True)
         params = self._rln_params_in_arena_order()
         if optimizer_idx == 0:  # unlabelled optimizer -> maximise entropy through the gradient-reversal layer
             loss, _, _ = TrainStepFn.apply(self, x_unlabelled, 0.1, drop_scales, seed, *params)

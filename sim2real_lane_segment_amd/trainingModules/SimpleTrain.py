@@ -15,6 +15,7 @@ from .TrainingBase import TrainingBase, getClassWeight  # noqa: F401
 class SimpleTrainModule(TrainingBase):
     def training_step(self, batch, batch_idx, drop_scales=None, seed=None):
         x, y = batch
+        x, y = self._rln_prepare_batch(x, y, train=True)
         params = self._rln_params_in_arena_order()
         loss, extra, probs = TrainStepFn.apply(self, x, y, drop_scales, seed, *params)
         if self.check_labels:

@@ -58,11 +58,21 @@ class TrainingBase(LightningModule, EngineOwner):
                            help="Ratio of maximum and minimum of learning rate for cosine LR scheduler")
         return parser
 
+    def _rln_prepare_batch(self, x, y=None, train=False):
+        """Device half of the input transform for batches that come from a DataLoader over the reference's datasets: the
+        Dataset-side MyTransform call hands over raw uint8 frames (dataManagement/myTransforms.py: deferred form); here
+        the whole batch goes through rln_preprocess_u8 / rln_augment_u8.  Float batches pass through untouched."""
+        if torch.is_tensor(x) and x.dtype == torch.uint8:
+            from ..dataManagement.myTransforms import MyTransform
+            return MyTransform.prepare_batch(x, y, train=train, device=self._rln_current_device())
+        return x, y
+
     def forward(self, x):
         """featureExtractor -> classifier as one fused HIP forward (TrainingBase.py:54-57).  In train mode with autograd
         enabled the result carries a grad_fn (HIP backward through the whole net), so a user-written step such as
         ``cross_entropy(self.forward(x), y).backward()`` (SimpleTrain.py:15-16) trains the parameters; in eval mode or
         under ``torch.no_grad()`` it is the plain inference forward."""
+        x, _ = self._rln_prepare_batch(x)
         if self.training and torch.is_grad_enabled():
             return ForwardFn.apply(self, x, None, None, *self._rln_params_in_arena_order())
         eng = self._rln_sync()
@@ -93,6 +103,7 @@ class TrainingBase(LightningModule, EngineOwner):
 
     def evaluate_batch(self, batch):
         x, y = batch
+        x, y = self._rln_prepare_batch(x, y)
         eng = self._rln_sync()
         with torch.no_grad():
             probs, _ = eng.forward(x, training=self.training, with_backward=False)

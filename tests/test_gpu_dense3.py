@@ -62,6 +62,45 @@ def test_dense3_forward(h, w, cin, cout, parts, dtype):
     assert torch.allclose(s[:, 1], (gsel * gsel).sum((0, 2, 3)), atol=1e-3, rtol=1e-4)
 
 
+@pytest.mark.parametrize("case", ["tiny_weights", "huge_activations", "tiny_activations"])
+def test_dense3_f16_range_handling(case):
+    """f16x2 (the default forward arithmetic) outside unit scale (csrc/split16.h): weights of 1e-4 keep the fp32-chain
+    accuracy class (packed times 2^8, un-scaled in the epilogue); activations beyond f16's largest finite value saturate at
+    65504 instead of turning into inf - inf = NaN; activations of 1e-4 keep an absolute error far below fp32 rounding of
+    the sums they enter."""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(77)
+    n, cin, cout, h, w = 2, 80, 16, 16, 80
+    x = torch.randn(n, cin, h, w, generator=g)
+    a = torch.rand(cin, generator=g) + 0.5
+    b = torch.randn(cin, generator=g) * 0.3
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    bias = torch.randn(cout, generator=g) * 0.1
+    if case == "tiny_weights":
+        wt = wt * 3e-3          # |w| ~ 1e-4
+        bias = bias * 3e-3
+    elif case == "huge_activations":
+        a = a * 4e4             # relu(a x + b) reaches ~1.5e5 > 65504
+    else:
+        a, b = a * 1e-4, b * 1e-4
+    z = F.relu(x * a[None, :, None, None] + b[None, :, None, None]).clamp(max=65504.0)
+    ref = F.conv2d(z.double(), wt.double(), bias.double(), padding=1)
+    out = torch.zeros((n, cout, h, w), device="cuda")
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    xd, wd, bd, ad, bbd = (t.cuda() for t in (x, wt, bias, a, b))
+    L.check(lib.rln_op_dense3_fwd(_p(xd), n, cin, cin, 0, h, w, _p(ad), _p(bbd), _p(wd), _p(bd), cout, None, _p(out), cout,
+                                  0, None, 2, 1, _p(ws), ws.numel(), _stream()))
+    torch.cuda.synchronize()
+    got = out.cpu().double()
+    assert torch.isfinite(got).all()
+    err = float((got - ref).abs().max()) / float(ref.abs().max())
+    # huge_activations: 37 % of the operands sit above 2^15 where even the two-part split has a 2^-22 relative step of
+    # values ~6e4; the bar is the same relative-to-max figure as at unit scale
+    assert err < TOL[(2, 1)], (case, err)
+    if case == "huge_activations":
+        assert float((z == 65504.0).double().mean()) > 0.01  # the saturation path is exercised
+
+
 def test_dense3_unsupported_geometry_is_reported():
     L, lib = _lib()
     x = torch.zeros(1, 16, 7, 10, device="cuda")

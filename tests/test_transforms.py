@@ -40,10 +40,16 @@ def test_device_transform_matches_oracle(hs, ws, h, w, gray):
         xr, yr = T.transform(frames[i], labels[i], width=w, height=h, gray=gray)
         np.testing.assert_array_equal(y[i].cpu().numpy(), yr)
         np.testing.assert_allclose(x[i].cpu().numpy(), xr, rtol=0, atol=1e-6)   # same uint8 pixel, float normalise
-    x1, y1 = tf(frames[0], labels[0])                                            # single-image call, as the reference
-    assert x1.shape == (3, h, w) and y1.shape == (h, w) and y1.dtype == torch.int64
-    x2, y2 = tf(frames[0])
-    assert y2 is None and torch.equal(x2, x1)
+    # single image + label from host memory = the Dataset protocol (myDatasets.py:59): deferred, no GPU work; the labels
+    # are final already (nearest resize by indexing), the frame goes through the device half per batch
+    x1, y1 = tf(frames[0], labels[0])
+    assert x1.dtype == torch.uint8 and not x1.is_cuda and tuple(x1.shape) == (hs, ws, 3)
+    assert y1.shape == (h, w) and y1.dtype == torch.int64 and not y1.is_cuda
+    np.testing.assert_array_equal(y1.numpy(), y[0].cpu().numpy())
+    xb, yb = MyTransform.prepare_batch(torch.stack([x1, x1]), torch.stack([y1, y1]), device="cuda")
+    assert torch.equal(xb[0], x[0]) and torch.equal(xb[1], x[0]) and torch.equal(yb[0].cpu(), y1)
+    x2, y2 = tf(frames[0])                                                       # no label: transforms at once (demo path)
+    assert y2 is None and torch.equal(x2, x[0])
 
 
 def test_aug_param_sampler_and_oracle_cpu():
@@ -110,3 +116,81 @@ def test_device_transform_errors():
     bad[0, 3:7] = [0, 0, 500, 600]
     with pytest.raises(ValueError):
         MyTransform(augment=True)(np.zeros((1, 48, 64, 3), np.uint8), params=bad)
+
+
+class _FrameFolder(torch.utils.data.Dataset):
+    """The access pattern of the reference's RightLaneDataset.__getitem__ (myDatasets.py:45-61): decoded uint8 frame and
+    mask from host memory -> self.transform(x, y)."""
+
+    def __init__(self, frames, labels, transform):
+        self.frames, self.labels, self.transform = frames, labels, transform
+
+    def __len__(self):
+        return len(self.frames)
+
+    def __getitem__(self, i):
+        y = self.labels[i] if self.labels is not None else torch.empty(0, dtype=torch.long)
+        return self.transform(self.frames[i], y)
+
+
+@pytest.mark.parametrize("augment", [False, True])
+def test_transform_inside_dataloader_workers_is_deferred(augment):
+    """DataLoader(num_workers=1, pin_memory=True) over a Dataset that calls MyTransform(x, y) per sample, as
+    dataManagement/dataModules.py:52-53 configures it: the call must not touch the GPU in the worker and must hand back
+    CPU tensors the loader can collate and pin.  Runs on the CPU-only build container."""
+    from sim2real_lane_segment_amd.dataManagement.myTransforms import MyTransform, nearest_resize_index
+    rng = np.random.default_rng(5)
+    frames = rng.integers(0, 256, size=(5, 48, 64, 3), dtype=np.uint8)
+    labels = rng.integers(0, 4, size=(5, 48, 64), dtype=np.uint8)
+    tf = MyTransform(width=16, height=12, augment=augment)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # "pin_memory ... no accelerator" on the CPU-only container
+        dl = torch.utils.data.DataLoader(_FrameFolder(frames, labels, tf), batch_size=2, shuffle=False, num_workers=1,
+                                         pin_memory=True)
+        batches = list(dl)
+    assert len(batches) == 3
+    x, y = batches[0]
+    assert x.dtype == torch.uint8 and tuple(x.shape) == (2, 48, 64, 3) and not x.is_cuda
+    np.testing.assert_array_equal(x.numpy(), frames[:2])
+    if augment:   # raw masks: the random crop is drawn per batch on the device side, image and mask together
+        assert y.dtype == torch.uint8 and tuple(y.shape) == (2, 48, 64)
+        np.testing.assert_array_equal(y.numpy(), labels[:2])
+    else:         # final labels: cv2 INTER_NEAREST by pure indexing
+        assert y.dtype == torch.int64 and tuple(y.shape) == (2, 12, 16)
+        sy, sx = nearest_resize_index(48, 12), nearest_resize_index(64, 16)
+        np.testing.assert_array_equal(y.numpy(), labels[:2][:, sy][:, :, sx].astype(np.int64))
+    # unlabelled dataset (haveLabels=False hands an empty long tensor through, myDatasets.py:56-57)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        xu, yu = next(iter(torch.utils.data.DataLoader(_FrameFolder(frames, None, tf), batch_size=2, num_workers=1)))
+    assert xu.dtype == torch.uint8 and tuple(yu.shape) == (2, 0)
+    # the device half refuses to run without a GPU instead of falling back to the CPU
+    with pytest.raises(RuntimeError, match="GPU only"):
+        MyTransform.prepare_batch(x, y, device="cpu")
+
+
+@pytest.mark.gpu
+def test_module_accepts_deferred_batches():
+    """A uint8 NHWC batch as the DataLoader delivers it goes through the device transform inside the module:
+    training_step (augmenting transform, raw masks), evaluate_batch and forward (plain transform, final labels)."""
+    from sim2real_lane_segment_amd.dataManagement.myTransforms import MyTransform
+    from sim2real_lane_segment_amd.trainingModules.SimpleTrain import SimpleTrainModule
+    rng = np.random.default_rng(11)
+    frames = rng.integers(0, 256, size=(2, 480, 640, 3), dtype=np.uint8)
+    labels = rng.integers(0, 4, size=(2, 480, 640), dtype=np.uint8)
+    t_train = MyTransform(augment=True, seed=3)
+    t_eval = MyTransform(augment=False)
+    model = SimpleTrainModule(num_cls=4).cuda().train()
+    xs, ys = zip(*[t_train(frames[i], labels[i]) for i in range(2)])
+    loss = model.training_step((torch.stack(xs), torch.stack(ys)), 0)
+    loss.backward()
+    assert torch.isfinite(loss) and model.featureExtractor.firstconv.weight.grad is not None
+    model.eval()
+    xe, ye = zip(*[t_eval(frames[i], labels[i]) for i in range(2)])
+    xe, ye = torch.stack(xe), torch.stack(ye)
+    ev = model.evaluate_batch((xe, ye))
+    assert set(ev) == {"loss", "acc", "dice", "iou", "weight"} and torch.isfinite(ev["loss"])
+    out = model(xe)                                             # test.py:93-94 calls forward on the loader's batch
+    ref_x, _ = t_eval(frames)                                   # immediate transform of the same frames
+    assert out.shape == (2, 4, 120, 160) and torch.equal(out, model(ref_x))
