@@ -225,16 +225,15 @@ def _sampled_grad_errors(eng, z):
     return per, float(np.sqrt(num / den))
 
 
-# (arithmetic, per-tensor bar, arena bar, median bar), set from what tools/grad_ref_probe.py measures on MI355X against this
-# fixture (random labels on a random-init net: the loss sits at ln 4 and every gradient is a cancelling sum, the
-# worst case for relative errors; the CPU oracle reproduces the reference's samples to 1e-6):
-#   exact-fp32 kernels        median 8.1e-4, p90 2.2e-3, max 3.9e-3 (full tensors) / 4.1e-3 (1024 samples), arena 7.7e-5
-#   default f16x2 / bf16x2    median 2.0e-3, p90 4.0e-3, max 1.1e-2 (a 288-element BatchNorm bias gradient on the 15x20
-#                             level whose fp32-vs-fp64 floor is 6.7e-5: 17-bit data-gradient products are 64x coarser than
-#                             fp32 on a sum that cancels to 1e-3 of its terms)
-#   bf16x3 / bf16x3           median 1.2e-3, p90 2.3e-3, max 6.6e-3
-# Bars = those figures with ~1.3x headroom, never below 5 x the tensor's own fp32-vs-fp64 noise floor.
-_TRAIN_MODES = [("fp32,fp32", 5e-3, 3e-4, 1.2e-3), (None, 1.5e-2, 1e-3, 3e-3)]
+# (arithmetic, per-tensor bar, arena bar, median bar), set from what is measured on MI355X against this fixture (random
+# labels on a random-init net: the loss sits at ln 4 and every gradient is a cancelling sum, the worst case for relative
+# errors; the CPU oracle reproduces the reference's samples to 1e-6; tools/grad_ref_probe.py lists every tensor):
+#   exact-fp32 kernels      median 8.1e-4, p90 2.2e-3, max 3.9e-3 (full tensors) / 4.1e-3 (1024 samples), arena 7.7e-5
+#   default f16x2 / bf16x2  median 7.8e-4, p90 1.5e-3, max 2.8e-3, arena 2.6e-4
+#     (before the 2^8 weight pre-scale of csrc/split16.h the low parts of the f16 weights were subnormal and this mode
+#      measured median 2.0e-3 / max 1.1e-2)
+# Bars = median <= 1.2e-3, every tensor <= max(5e-3, 5 x its own fp32-vs-fp64 noise floor), whole arena <= 3e-4 / 5e-4.
+_TRAIN_MODES = [("fp32,fp32", 5e-3, 3e-4, 1.2e-3), (None, 5e-3, 5e-4, 1.2e-3)]
 
 
 @pytest.mark.parametrize("arith,tensor_bar,arena_bar,median_bar", _TRAIN_MODES, ids=["exact_fp32", "default"])
@@ -361,12 +360,12 @@ def test_two_domain_batch8_train_step_vs_oracle():
         errs.append(l2)
         num += float((got - g).double().pow(2).sum())
         den += float(g.double().pow(2).sum())
-        if not l2 < grad_l2_bar("fcd67_2x120x160", k):
+        if not l2 < 3e-3:  # structured frames: measured median 1.6e-4, max 1.5e-3
             bad.append((k, l2))
     print(f"[two-domain] gradient L2-relative error vs the oracle: median {np.median(errs):.2e}, max {max(errs):.2e}, "
           f"arena {np.sqrt(num / den):.2e}; domains {dom.tolist()}")
     assert not bad, f"{len(bad)} gradient tensors off: {bad[:10]}"
-    assert np.sqrt(num / den) < 1.5e-3
+    assert np.sqrt(num / den) < 5e-4 and float(np.median(errs)) < 5e-4
 
 
 def test_full_size_properties_batch64():
@@ -535,11 +534,12 @@ def test_named_variants_train_step_vs_oracle(variant):
     loss, acc, grads, probs_ref = O.train_step(ts, x, y, cfg, scales, apply_update=False)
     assert abs(float(out[0]) - float(loss)) < 2e-4
     np.testing.assert_allclose(probs.cpu().numpy(), probs_ref.numpy(), atol=1e-3)
-    # Per tensor: max(6e-3, 5 x the tensor's own fp32-vs-fp64 noise floor), capped at 5e-2.  Tensors whose floor alone
-    # exceeds 1e-2 (fp32 itself does not pin them: 64x96 inputs leave 2x3-pixel maps at the bottom of a 100-layer net)
-    # cannot meet a capped bar by construction; they are listed, counted and held to 8 x their floor instead.
+    # Every tensor within 1e-2 L2-relative and the whole arena within 1e-3, whatever the tensor's own fp32-vs-fp64 noise
+    # floor says (FCDenseNet103 at 64x96 has 21 tensors whose floor alone is above 1e-2: 2x3-pixel maps at the bottom of a
+    # 100-layer net).  Measured on MI355X: FCDenseNet57 median 7.7e-4 / max 7.5e-3 / arena 1.9e-4, FCDenseNet103
+    # median 9.4e-4 / max 4.9e-3 / arena 4.8e-4 -- the ill-conditioned tensors sit at 1.7e-3, well inside their floor.
     table = f"fcd{variant}_2x64x96"
-    bad, listed, errs = [], [], []
+    bad, errs = [], []
     num = den = 0.0
     for k, g in grads.items():
         got = eng.grad_views[k].cpu()
@@ -548,20 +548,13 @@ def test_named_variants_train_step_vs_oracle(variant):
         errs.append(l2)
         num += float((got - g).double().pow(2).sum())
         den += float(g.double().pow(2).sum())
-        nf = _noise_floor(table, k)
-        if 5.0 * nf > GRAD_BAR_CAP:
-            listed.append((k, l2, nf))
-            if not l2 < 8.0 * nf:
-                bad.append((k, l2, nf))
-        elif not l2 < grad_l2_bar(table, k):
-            bad.append((k, l2, nf))
+        if not l2 < 1e-2:
+            bad.append((k, l2, _noise_floor(table, k)))
     errs = np.array(errs)
     print(f"[fcd{variant}] gradient L2-relative error vs the oracle: median {np.median(errs):.2e}, p90 "
-          f"{np.quantile(errs, 0.9):.2e}, max {errs.max():.2e}, arena {np.sqrt(num / den):.2e}; {len(listed)} tensors with "
-          f"a noise floor above {GRAD_BAR_CAP / 5:.0e} (held to 8 x floor): {[(k, round(e, 4), round(f, 4)) for k, e, f in listed]}")
+          f"{np.quantile(errs, 0.9):.2e}, max {errs.max():.2e}, arena {np.sqrt(num / den):.2e}")
     assert not bad, f"{len(bad)} gradient tensors off: {bad[:10]}"
-    assert len(listed) <= {"57": 0, "103": 21}[variant]
-    assert np.sqrt(num / den) < 3e-3
+    assert np.sqrt(num / den) < 1e-3 and float(np.median(errs)) < 2e-3
 
 
 def test_differentiable_module_forward_matches_fused_step():
