@@ -60,7 +60,7 @@ struct D3Fwd {
 };
 // true when the launch geometry is supported (W % 4 == 0, 16-byte aligned planes, W >= 40, Cout <= 16)
 bool d3_fwd_supported(const D3Fwd& p);
-void d3_fwd_pick_tile(int H, int W, int np, int* th, int* tw, int* rg);
+void d3_fwd_pick_tile(int H, int W, int np, int* th, int* tw, int* rg, int st = 0);
 int d3_fwd_launch(const D3Fwd& p, int N, int np, int dt, hipStream_t s);
 
 // ---- weight gradient -------------------------------------------------------------------------------------------------
@@ -115,12 +115,13 @@ struct D3Pull {
   int acc_lo, acc_hi;             // channels in [acc_lo, acc_hi) accumulate into G, the others overwrite
   int H, W, N;
   int th, tw, tiles_x, tiles_y;
-  float* stat_partial;            // [2*blocks][nl][Cpad][2], Cpad = 16*ceil(C/16) (two rows per block)
+  float* stat_partial;            // [nsub*blocks][nl][Cpad][2], Cpad = 16*ceil(C/16), nsub = d3_pull_nsub()
   int st;                         // storage element type of S and of the dY buffers (storage.h); G is fp32
 };
 bool d3_pull_supported(const D3Pull& p, int np);  // geometry + LDS budget (set nl, C, th, tw first)
 void d3_pull_pick_tile(int H, int W, int* th, int* tw);
-int d3_pull_blocks(const D3Pull& p);  // persistent grid size; stat_partial holds 2 rows per block
+int d3_pull_blocks(const D3Pull& p);  // persistent grid size
+int d3_pull_nsub(const D3Pull& p);    // stat_partial rows per block (2, or 5 for a one-group launch)
 int d3_pull_launch(const D3Pull& p, int np, int dt, hipStream_t s);
 // reduces the partial rows of a pull launch: dbeta_j[c] = sum gz_j, dgamma_j[c] = sum gz_j*xhat (c < C) and adds the
 // gamma-weighted sums of all layers into the level accumulators S1/S2 (fixed summation order)

@@ -172,7 +172,10 @@ __global__ __launch_bounds__(768, 3) void d3_fwd_k(const D3Fwd p) {
     // counters.  Two register sets hold the chunks of even / odd iteration: a chunk's loads stay in flight for two
     // iterations (~130 KB per CU outstanding).
     const int ptid = tid - 256;
-    const int nq = p.tw >> 2;
+    // pixels per staging unit.  (16-byte loads of 8 bf16 pixels were measured: no faster than 8-byte loads of 4 -- the
+    // request width is not what limits this kernel -- and twice the staging registers.)
+    constexpr int PXU = 4;
+    const int nq = p.tw / PXU;
     const int rgs = p.rg == 2 ? 1 : 2;        // log2(rows per 8-lane group)
     const int qpg = 4 >> rgs;                 // quads per group
     const int nqg = (nq + qpg - 1) / qpg;     // groups per row band
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(768, 3) void d3_fwd_k(const D3Fwd p) {
       const int o = lu & 1, rr = (lu >> 1) & (p.rg - 1), qq = (lu >> (1 + rgs)) & (qpg - 1), u = lu >> 3;
       const int R = u / nqg, Q = (u - R * nqg) * qpg + qq;
       const int r = (R << rgs) + rr;
-      const int iy = gy0 - 1 + r, ix = gx0 + 4 * Q;
+      const int iy = gy0 - 1 + r, ix = gx0 + PXU * Q;
       bool ok = (R < nrg) && (r < rows) && (Q < nq) && (iy >= 0) && (iy < p.H) && (ix < p.W);
 #ifdef RLN_DIAG
       if ((p.dbg & 16) && (r == 0 || r == rows - 1)) ok = false;  // timing ablation: no halo rows
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(768, 3) void d3_fwd_k(const D3Fwd p) {
       const int goff = ok ? iy * p.W + ix : 0;
 #pragma unroll
       for (int cc = 0; cc < 8; ++cc) s_off[cc] = (o * 8 + cc) * p.cs + goff;  // relative to the chunk's first plane
-      s_lds = ((ok ? r : 0) * P + 1 + 4 * (ok ? Q : 0)) * 32 + o * 16;
+      s_lds = ((ok ? r : 0) * P + 1 + PXU * (ok ? Q : 0)) * 32 + o * 16;
       s_o = o;
     }
     // halo columns: unit = (row, side, channel pair)
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(768, 3) void d3_fwd_k(const D3Fwd p) {
       typename SRaw<ST>::r1 h[2];
       uint4 b[NB];
     };
-    Stage RA, RB;
+    Stage RA;
     // the tail chunk of a Cin that is no multiple of 16 starts at Cin-16 (see d3_pack_k): no clamping needed
     auto chunk_base = [&](int chunk) __attribute__((always_inline)) { return min(chunk * 16, max(p.Cin - 16, 0)); };
     auto issue = [&](int chunk, Stage& R) __attribute__((always_inline)) {
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(768, 3) void d3_fwd_k(const D3Fwd p) {
         const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
         const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-        for (int px = 0; px < 4; ++px) {
+        for (int px = 0; px < PXU; ++px) {
           unsigned parts[4][NP];
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
@@ -268,10 +271,15 @@ __global__ __launch_bounds__(768, 3) void d3_fwd_k(const D3Fwd p) {
         }
       }
     };
-    // chunk c_begin+i lives in set i & 1.  Iteration i (consumers multiply chunk i): commit chunk i+1 into the other
-    // LDS buffer, refill its register set with chunk i+3.
     const int nck = c_end - c_begin;
     auto bufof = [&](int i) __attribute__((always_inline)) { return smem + ((c_begin + i) & 1) * IMG; };
+    // (Measured with bf16 stacks and not kept: four register sets = loads in flight for four iterations, -7 %; 16-byte
+    // loads of 8 pixels per lane, +-0; 320-pixel column tiles with one register set and two workgroups per CU, -18 %.
+    // In steady state the kernel moves 4.0 - 4.6 TB/s of its strip pattern; what is left is the fill / drain of the
+    // 7.5 consecutive blocks per CU of a level-0 launch.)
+    // chunk c_begin+i lives in set i & 1.  Iteration i (consumers multiply chunk i): commit chunk i+1 into the other
+    // LDS buffer, refill its register set with chunk i+3.
+    Stage RB;
     if (nck > 0) issue(c_begin, RA);
     if (nck > 1) issue(c_begin + 1, RB);
     lds_setup();
@@ -423,8 +431,10 @@ bool d3_fwd_supported(const D3Fwd& p) {
 
 // Tiles are full-width strips whenever a row fits (W <= 160): every (channel, tile) region is then ONE contiguous run
 // of (th+2)*W floats in HBM (no column halo; DRAM-page friendly), which streams about twice as fast as column tiles.
-void d3_fwd_pick_tile(int H, int W, int np, int* th, int* tw, int* rg) {
+void d3_fwd_pick_tile(int H, int W, int np, int* th, int* tw, int* rg, int st) {
   (void)H;
+  const int pxu = 4;  // pixels per staging unit
+  (void)st;
   if (W <= 160) {  // (8 x 80 column tiles at W = 160 were measured 4 % slower than 4 x 160 strips)
     *tw = W;
     const int cap = np >= 3 ? 320 : 640;  // pixels per tile (LDS: two image buffers)
@@ -438,7 +448,7 @@ void d3_fwd_pick_tile(int H, int W, int np, int* th, int* tw, int* rg) {
   // rows per staging lane group: 4 (conflict-free LDS writes) unless 2 saves a staging round
   auto units = [&](int g) {
     const int qpg = 4 / g;
-    return 8 * ((*th + 2 + g - 1) / g) * ((*tw / 4 + qpg - 1) / qpg);
+    return 8 * ((*th + 2 + g - 1) / g) * ((*tw / pxu + qpg - 1) / qpg);
   };
   *rg = units(4) <= 512 ? 4 : 2;  // 512 producer threads, one unit each
 }
@@ -470,9 +480,10 @@ int d3_fwd_launch(const D3Fwd& p, int N, int np, int dt, hipStream_t s) {
   // tile capacity: 64*MPW pixels; staging rounds NR = ceil(8 * ceil((th+2)/4) * (tw/4) / 256)
   const int npix = p.th * p.tw;
   const int qpg = 4 / p.rg;
-  const int lane_units = 8 * ((p.th + 2 + p.rg - 1) / p.rg) * ((p.tw / 4 + qpg - 1) / qpg);
+  const int pxu = 4;
+  const int lane_units = 8 * ((p.th + 2 + p.rg - 1) / p.rg) * ((p.tw / pxu + qpg - 1) / qpg);
   const int nr = 1;
-  if ((p.th + 2) * 16 > 512 || lane_units > 512 || (p.tw & 3) || (p.rg != 2 && p.rg != 4)) return -4;
+  if ((p.th + 2) * 16 > 512 || lane_units > 512 || (p.tw % pxu) || (p.rg != 2 && p.rg != 4)) return -4;
 #define D3_FWD(MPW_, NR_)                                                                         \
   do {                                                                                            \
     if (p.st == ST_BF16) {                                                                        \
@@ -885,10 +896,13 @@ int d3_wgrad_launch(const D3Wgrad& p, int np, int dt, hipStream_t s) {
 // per-(layer, channel) slots in LDS.  G is written once per group.  Two waves per SIMD: one wave's epilogue VALU work
 // overlaps the other's MFMAs.
 // =============================================================================================
-template <int NP, int DT, int ST>
+template <int NP, int DT, int ST, int MT>
 __global__ __launch_bounds__(512, 2) void d3_pull_k(const D3Pull p) {
   extern __shared__ __align__(16) unsigned char smem[];
-  constexpr int MT = 5;  // M-tiles per work item: an item = (output-channel group, half of the 160-pixel tile)
+  // MT M-tiles per work item: an item = (output-channel group, 1/NSUB of the 160-pixel tile).  MT = 5 (halves) for the
+  // wide input ranges of a block; MT = 2 (fifths) when the launch covers one 16-channel group (a block's own new
+  // channels), so that five of the eight waves have work instead of two.
+  constexpr int NSUB = 10 / MT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lp = lane & 15, lg = lane >> 4;
   const int P = p.tw + 3;
@@ -897,10 +911,10 @@ __global__ __launch_bounds__(512, 2) void d3_pull_k(const D3Pull p) {
   const int LIMG = NP * PLANE;  // one layer's image
   const int ngroups = (p.C + 15) >> 4;
   const int Cpad = ngroups * 16;
-  float* stats = reinterpret_cast<float*>(smem + p.nl * LIMG);  // [half][nl][Cpad][2]
-  float* ctab = stats + 2 * p.nl * Cpad * 2;                     // [nl][Cpad][4]: ea, eb, gamma, - ; then [Cpad][2] mean, invstd
+  float* stats = reinterpret_cast<float*>(smem + p.nl * LIMG);  // [sub][nl][Cpad][2]
+  float* ctab = stats + NSUB * p.nl * Cpad * 2;                  // [nl][Cpad][4]: ea, eb, gamma, - ; then [Cpad][2] mean, invstd
   float* mtab = ctab + p.nl * Cpad * 4;
-  for (int i = tid; i < 2 * p.nl * Cpad * 2; i += 512) stats[i] = 0.f;
+  for (int i = tid; i < NSUB * p.nl * Cpad * 2; i += 512) stats[i] = 0.f;
   for (int i = tid; i < p.nl * Cpad; i += 512) {  // per-(layer, channel) constants: tile-invariant, read from LDS later
     const int j = i / Cpad, ch = min(i - j * Cpad, p.C - 1);
     ctab[i * 4 + 0] = p.ea[j][ch];
@@ -1019,8 +1033,8 @@ __global__ __launch_bounds__(512, 2) void d3_pull_k(const D3Pull p) {
     uint4 bf[5][NP];
     bool bf_valid = false;
 #pragma unroll 1
-    for (int item = wave; item < 2 * ngroups; item += 8) {
-      const int g = item >> 1, half = item & 1;
+    for (int item = wave; item < NSUB * ngroups; item += 8) {
+      const int g = item / NSUB, half = item - g * NSUB;  // "half" = which 1/NSUB of the tile
       int basem[MT], goff[MT];
       unsigned vmask = 0;
 #pragma unroll
@@ -1065,8 +1079,8 @@ __global__ __launch_bounds__(512, 2) void d3_pull_k(const D3Pull p) {
         // weight fragments of the NEXT (item, layer): each k-step's registers are refilled as soon as the step is done,
         // so the L2 latency of the 10 KB per (group, layer) hides behind the remaining steps and the epilogue
         const bool last_layer = j + 1 == p.nl;
-        const int gn = last_layer ? ((item + 8) >> 1) : g;
-        const bool has_next = !last_layer || (item + 8 < 2 * ngroups);
+        const int gn = last_layer ? ((item + 8) / NSUB) : g;
+        const bool has_next = !last_layer || (item + 8 < NSUB * ngroups);
         const uint4* wpn = p.wpk[last_layer ? 0 : j + 1] + ((long long)(has_next ? gn : g) * 5 * NP) * 64 + lane;
         const float4 cst = *reinterpret_cast<const float4*>(ctab + ((long long)j * Cpad + g * 16 + lp) * 4);
         const float ea = cst.x, eb = cst.y, egam = cst.z;
@@ -1144,9 +1158,9 @@ __global__ __launch_bounds__(512, 2) void d3_pull_k(const D3Pull p) {
     }
   }
   __syncthreads();
-  if (p.stat_partial != nullptr) {  // rows: [block][half]
-    float* dst = p.stat_partial + (long long)blockIdx.x * 2 * p.nl * Cpad * 2;
-    for (int i = tid; i < 2 * p.nl * Cpad * 2; i += 512) dst[i] = stats[i];
+  if (p.stat_partial != nullptr) {  // rows: [block][sub]
+    float* dst = p.stat_partial + (long long)blockIdx.x * NSUB * p.nl * Cpad * 2;
+    for (int i = tid; i < NSUB * p.nl * Cpad * 2; i += 512) dst[i] = stats[i];
   }
 }
 
@@ -1186,10 +1200,13 @@ int d3_pull_finalize(const D3PullFin& f, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
+int d3_pull_nsub(const D3Pull& p) { return p.C <= 16 ? 5 : 2; }  // work items per (group, tile): see d3_pull_k
+
 static size_t d3_pull_lds(const D3Pull& p, int np) {
   const int P = p.tw + 3, rows = p.th + 2;
   const int Cpad = ((p.C + 15) / 16) * 16;
-  return (size_t)p.nl * np * rows * P * 32 + (size_t)2 * p.nl * Cpad * 2 * 4 + (size_t)p.nl * Cpad * 16 + (size_t)Cpad * 8;
+  return (size_t)p.nl * np * rows * P * 32 + (size_t)d3_pull_nsub(p) * p.nl * Cpad * 2 * 4 + (size_t)p.nl * Cpad * 16 +
+         (size_t)Cpad * 8;
 }
 
 bool d3_pull_supported(const D3Pull& p, int np) {
@@ -1221,11 +1238,11 @@ int d3_pull_blocks(const D3Pull& p) {
   return (int)std::min<long long>(total, 256);
 }
 
-template <int NP, int DT, int ST = ST_F32>
-static int d3_pull_launch_t(const D3Pull& p, hipStream_t s) {
+template <int NP, int DT, int ST, int MT>
+static int d3_pull_launch_m(const D3Pull& p, hipStream_t s) {
   const size_t lds = d3_pull_lds(p, NP);
   if (lds > 160 * 1024) return -4;
-  auto kern = d3_pull_k<NP, DT, ST>;
+  auto kern = d3_pull_k<NP, DT, ST, MT>;
   static DevOnce attr_once;
   if (attr_once.first()) {
     const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1238,6 +1255,11 @@ static int d3_pull_launch_t(const D3Pull& p, hipStream_t s) {
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)d3_pull_blocks(p)), dim3(512), lds, s, p);
   return (int)hipGetLastError();
+}
+
+template <int NP, int DT, int ST = ST_F32>
+static int d3_pull_launch_t(const D3Pull& p, hipStream_t s) {
+  return d3_pull_nsub(p) == 5 ? d3_pull_launch_m<NP, DT, ST, 2>(p, s) : d3_pull_launch_m<NP, DT, ST, 5>(p, s);
 }
 
 int d3_pull_launch(const D3Pull& p, int np, int dt, hipStream_t s) {

@@ -518,7 +518,7 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
       }
       if (o.type == OP_DENSE && c->d3_fwd_np > 0) {
         int dth, dtw, drg;
-        d3_fwd_pick_tile(Hd, Wd, c->d3_fwd_np, &dth, &dtw, &drg);
+        d3_fwd_pick_tile(Hd, Wd, c->d3_fwd_np, &dth, &dtw, &drg, lst[o.dst_level]);
         stat_max = std::max(stat_max, (size_t)n * ((Hd + dth - 1) / dth) * ((Wd + dtw - 1) / dtw) * o.cout * 2);
       }
       if (o.type == OP_DENSE) {
@@ -982,7 +982,7 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
     q.ksplit = 1;
     q.st = dl.st;
     if (d3_fwd_supported(q)) {
-      d3_fwd_pick_tile(q.H, q.W, c->d3_fwd_np, &q.th, &q.tw, &q.rg);
+      d3_fwd_pick_tile(q.H, q.W, c->d3_fwd_np, &q.th, &q.tw, &q.rg, q.st);
       q.tiles_y = (q.H + q.th - 1) / q.th;
       q.tiles_x = (q.W + q.tw - 1) / q.tw;
       int e3;
@@ -1853,11 +1853,73 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
   for (int j = 0; j < L; ++j)
     if (c->d3_wb_off[(size_t)k0 + j] < 0) return kNotCovered;
 
+  // The block's own new channels in pull form too (16-channel groups on the packed-weight grid): group j = the output
+  // of layer j is consumed by the layers i > j of the block; once those are finalised, ONE launch pulls their
+  // contributions into G[group j] (S read once, G written once, nothing read-modify-written per layer), and only then is
+  // dY_j finalised.  Falls back to the per-layer exact-fp32 kernel when the channel grid does not line up.
+  const Op& last_op = c->ops[(size_t)k1];
+  const int gr = first.cout;
+  // Measured on MI355X (batch 64): the one-group launches are latency-bound (30 tiles per block, each paying a full load
+  // round trip: 113 us per launch whatever the layer count) and the form loses 1.1 ms per step against the per-layer
+  // kernel; it stays available to diagnostic builds (RLN_PULL_NEW).
+  const bool pull_new = gr == 16 && (C0 % 16) == 0 && L - 1 <= D3_LMAX && rln_env("RLN_PULL_NEW") != nullptr;
+  auto pull_range = [&](int ch_lo, int C, int i_lo, int i_hi, int acc_lo, int acc_hi) -> int {
+    // input channels [ch_lo, ch_lo + C) of the block (relative to its first input channel) from layers i_hi .. i_lo
+    D3Pull g = q;
+    D3PullFin f;
+    memset(&f, 0, sizeof(f));
+    const int nl = i_hi - i_lo + 1;
+    g.nl = nl;
+    g.C = C;
+    g.S = lv.sp(first.in_off + ch_lo);
+    g.G = lv.G + (size_t)(first.in_off + ch_lo) * plane;
+    g.mean = c->mean + lv.stat_off + first.in_off + ch_lo;
+    g.invstd = c->invstd + lv.stat_off + first.in_off + ch_lo;
+    for (int i = 0; i < nl; ++i) {
+      const int j = i_hi - i;
+      const Op& o = c->ops[(size_t)k0 + j];
+      g.dY[i] = c->dyblk[(size_t)j];
+      g.wpk[i] = c->d3_packed + c->d3_wb_off[(size_t)k0 + j] + (long long)(ch_lo / 16) * 5 * c->d3_bwd_np * 64;
+      g.ea[i] = c->ab + o.bn.ab + ch_lo;
+      g.eb[i] = c->ab + c->n_ab + o.bn.ab + ch_lo;
+      g.egamma[i] = c->params + o.bn.gamma + ch_lo;
+      f.gamma[i] = c->params + o.bn.gamma + ch_lo;
+      f.dgamma[i] = c->grads + o.bn.gamma + ch_lo;
+      f.dbeta[i] = c->grads + o.bn.beta + ch_lo;
+    }
+    g.acc_lo = acc_lo;
+    g.acc_hi = acc_hi;
+    g.stat_partial = c->stat_partial;
+    if (!d3_pull_supported(g, c->d3_bwd_np)) return fail(RLN_ERR_UNSUPPORTED, "pull launch not covered");
+    {
+      const double flops = 2.0 * C * first.cout * 9.0 * plane * N * nl;
+      const double eb = (double)st_bytes(lv.st);  // dY and S in the level's storage type, G in fp32
+      const double bytes = (double)N * plane * (eb * nl * first.cout + (eb + 4.0) * C + 4.0 * (acc_hi - acc_lo));
+      ProfScope ps(c, PC_D3_PULL, flops, bytes, s);
+      RLN_TRY(d3_pull_launch(g, c->d3_bwd_np, c->d3_bwd_dt, s));
+    }
+    f.nl = nl;
+    f.C = C;
+    f.Cpad = ((C + 15) / 16) * 16;
+    f.rows = d3_pull_nsub(g) * d3_pull_blocks(g);
+    f.partial = c->stat_partial;
+    f.S1 = c->S1 + lv.stat_off + first.in_off + ch_lo;
+    f.S2 = c->S2 + lv.stat_off + first.in_off + ch_lo;
+    ProfScope psb(c, PC_BN, 0, 0, s);
+    RLN_TRY(d3_pull_finalize(f, s));
+    return 0;
+  };
+
   for (int j = L - 1; j >= 0; --j) {
     const Op& o = c->ops[(size_t)k0 + j];
     long long rows = 0;
     const float* nscale = (o.drop_ch >= 0) ? (c->masks + (size_t)N * o.drop_ch) : nullptr;
     float* dYj = c->dyblk[(size_t)j];
+    if (pull_new && j < L - 1) {  // G[group j] += contributions of layers j+1 .. L-1 (all finalised by now)
+      const int lo = C0 + gr * j;
+      const int alo = std::min(std::max(last_op.acc_lo - lo, 0), gr), ahi = std::min(std::max(last_op.acc_hi - lo, 0), gr);
+      RLN_TRY(pull_range(lo, gr, j + 1, L - 1, alo, ahi));
+    }
     RLN_TRY(finalize_grad_range(c, o.dst_level, o.out_off, o.cout, nscale, &rows, s, dYj));
     // the layer's three small reductions (bias rows, weight slabs, BatchNorm-backward sums of its new-channel data
     // gradient) run as ONE launch at the end of the iteration when the weight gradient went through d3_wgrad_k
@@ -1926,7 +1988,7 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
         RLN_TRY(run_wgrad(c, WG_DENSE3, w, o.cout, o.cin, o.conv.w, s));
       }
     }
-    const int Jn = o.cin - C0;  // new channels this layer consumes
+    const int Jn = pull_new ? 0 : o.cin - C0;  // new channels this layer consumes (per-layer form only)
     if (Jn > 0) {
       IgemmParams p;
       memset(&p, 0, sizeof(p));
@@ -2036,7 +2098,7 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
     f.nl = nl;
     f.C = C0;
     f.Cpad = ((C0 + 15) / 16) * 16;
-    f.rows = 2 * d3_pull_blocks(q);
+    f.rows = d3_pull_nsub(q) * d3_pull_blocks(q);
     f.partial = c->stat_partial;
     f.S1 = c->S1 + lv.stat_off + first.in_off;
     f.S2 = c->S2 + lv.stat_off + first.in_off;

@@ -32,11 +32,17 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
 
 template <int ST>
 struct SRaw;  // the registers a load of 1 / 2 / 4 consecutive elements occupies before it is widened
+// rq = ONE 16-byte load (a full-width request per lane: half-width loads leave the per-CU request queues as the limit
+// and buy no bandwidth); it holds QN consecutive elements, q(v, i) widens element i (i a compile-time constant after
+// unrolling).
 template <>
 struct SRaw<ST_F32> {
   typedef float r1;
   typedef float2 r2;
   typedef float4 r4;
+  typedef float4 rq;
+  static constexpr int QN = 4;
+  static __device__ __forceinline__ float q(const rq& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
   static __device__ __forceinline__ float w1(r1 v) { return v; }
   static __device__ __forceinline__ float2 w2(r2 v) { return v; }
   static __device__ __forceinline__ float4 w4(r4 v) { return v; }
@@ -46,6 +52,12 @@ struct SRaw<ST_BF16> {
   typedef unsigned short r1;
   typedef unsigned r2;
   typedef uint2 r4;
+  typedef uint4 rq;
+  static constexpr int QN = 8;
+  static __device__ __forceinline__ float q(const rq& v, int i) {
+    const unsigned w = (i >> 1) == 0 ? v.x : (i >> 1) == 1 ? v.y : (i >> 1) == 2 ? v.z : v.w;
+    return (i & 1) ? bf16_hi(w) : bf16_lo(w);
+  }
   static __device__ __forceinline__ float w1(r1 v) { return __builtin_bit_cast(float, (unsigned)v << 16); }
   static __device__ __forceinline__ float2 w2(r2 v) { return make_float2(bf16_lo(v), bf16_hi(v)); }
   static __device__ __forceinline__ float4 w4(r4 v) {
@@ -75,6 +87,9 @@ struct SP {
   }
   __device__ __forceinline__ typename R::r4 raw4(long long i = 0) const {
     return *reinterpret_cast<const typename R::r4*>(p + i * ES);
+  }
+  __device__ __forceinline__ typename R::rq rawq(long long i = 0) const {  // 16 bytes = R::QN elements
+    return *reinterpret_cast<const typename R::rq*>(p + i * ES);
   }
   // ... or widened at once
   __device__ __forceinline__ float ld1(long long i = 0) const { return R::w1(raw1(i)); }

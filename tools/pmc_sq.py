@@ -8,7 +8,7 @@ for d in sys.argv[1:]:
             k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void rln::", "").replace("rln::", "")
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
 names = sorted({c for v in agg.values() for c in v})
-top = sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0))[:12]
+top = sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0))[:14]
 for k, v in top:
     wc = v.get("SQ_WAVE_CYCLES", 0) or 1
     print(f"\n== {k[:70]}   SQ_WAVE_CYCLES {wc:.3e}")
