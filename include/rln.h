@@ -270,6 +270,10 @@ int rln_op_bn_drop_upsample2(const float* x, int n, int c, int h, int w, const f
                              const float* mask, float* out, void* stream);
 int rln_op_softmax_channels(const float* x, int n, int c, int hw, float* out, void* stream);
 int rln_op_dropout_mask(float* dst, int64_t count, float keep, uint64_t seed, void* stream);
+/* rln_op_scaled_softmax: the tail of FCDenseNetClassifier.forward (tiramisu.py:120-125) for classifiers whose finalConv is
+ * not 1x1 (FCDenseNet57(n_classes, kernel_size), tiramisu.py:113-115,150): out = softmax over channels of x / T
+ * (use_softmax) or x / T, on the [n][c][hw] logits rln_op_conv_act produced. */
+int rln_op_scaled_softmax(const float* x, int n, int c, int hw, float T, int use_softmax, float* out, void* stream);
 
 /* rln_preprocess_u8: the non-augmenting input transform of dataManagement/myTransforms.py:15-19 on device:
  * Resize(h, w) [bilinear, cv2 INTER_LINEAR fixed point for 8-bit] -> optional ToGray -> Normalize(mean, std, 255) ->

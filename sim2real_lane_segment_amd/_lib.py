@@ -102,6 +102,7 @@ _PROTOS = {
                                          c_void_p]),
     "rln_op_softmax_channels": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rln_op_dropout_mask": (c_int, [c_void_p, c_int64, c_float, c_uint64, c_void_p]),
+    "rln_op_scaled_softmax": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p]),
     "rln_preprocess_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, POINTER(c_float),
                                   POINTER(c_float), c_void_p, c_void_p, c_void_p]),
     "rln_augment_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, POINTER(c_float),

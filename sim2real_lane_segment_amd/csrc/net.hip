@@ -3095,6 +3095,12 @@ int rln_overlay_u8(const uint8_t* frames, int n, int hs, int ws, const float* pr
   return 0;
 }
 
+int rln_op_scaled_softmax(const float* x, int n, int c, int hw, float T, int use_softmax, float* out, void* stream) {
+  if (!(T > 0.f) || n < 1 || c < 1 || hw < 1) return fail(RLN_ERR_ARG, "bad arguments");
+  RLN_TRY(softmax_channels(x, n, c, hw, out, (hipStream_t)stream, T, use_softmax));
+  return 0;
+}
+
 int rln_op_dropout_mask(float* dst, int64_t count, float keep, uint64_t seed, void* stream) {
   RLN_TRY(dropout_scales(dst, count, keep, (unsigned long long)seed, (hipStream_t)stream));
   return 0;

@@ -129,7 +129,8 @@ int bn_drop_maxpool(const float* x, int N, int C, int H, int W, const float* a, 
 // y = mask * (a[c]*x + b[c]); then UpsamplingBilinear2d(scale_factor=2) (align_corners=True)
 int bn_drop_upsample2(const float* x, int N, int C, int H, int W, const float* a, const float* b, const float* mask,
                       float* out, hipStream_t s);
-int softmax_channels(const float* x, int N, int C, int HW, float* out, hipStream_t s);
+// out = softmax over channels of x / T (use_softmax) or x / T
+int softmax_channels(const float* x, int N, int C, int HW, float* out, hipStream_t s, float T = 1.f, int use_softmax = 1);
 // input transform (myTransforms.py:15-19): uint8 HWC frames -> resized, normalised float CHW (+ nearest-resized labels)
 int preprocess_u8(const unsigned char* frames, int N, int hs, int ws, const unsigned char* labels, int h, int w, int gray,
                   const float* mean3, const float* std3, float* x, long long* y, hipStream_t s);

@@ -1410,22 +1410,29 @@ int bn_drop_upsample2(const float* x, int N, int C, int H, int W, const float* a
   RLN_LAUNCH_CHECK();
 }
 
-__global__ __launch_bounds__(256) void softmax_channels_k(const float* __restrict__ x, int C, long long HW, float* out) {
+// out = softmax over channels of (x / T) (use_softmax) or x / T; T = 1 is the plain Softmax(dim=-3) of EncDecNet.py:97
+__global__ __launch_bounds__(256) void softmax_channels_k(const float* __restrict__ x, int C, long long HW, float T,
+                                                          int use_softmax, float* out) {
   const int n = blockIdx.y;
   const long long px = (long long)blockIdx.x * 256 + threadIdx.x;
   if (px >= HW) return;
   const float* xp = x + (long long)n * C * HW + px;
-  float m = xp[0];
-  for (int c = 1; c < C; ++c) m = fmaxf(m, xp[(long long)c * HW]);
-  float sum = 0.f;
-  for (int c = 0; c < C; ++c) sum += expf(xp[(long long)c * HW] - m);
-  const float inv = 1.f / sum;
   float* op = out + (long long)n * C * HW + px;
-  for (int c = 0; c < C; ++c) op[(long long)c * HW] = expf(xp[(long long)c * HW] - m) * inv;
+  if (!use_softmax) {
+    for (int c = 0; c < C; ++c) op[(long long)c * HW] = xp[(long long)c * HW] / T;
+    return;
+  }
+  float m = xp[0] / T;
+  for (int c = 1; c < C; ++c) m = fmaxf(m, xp[(long long)c * HW] / T);
+  float sum = 0.f;
+  for (int c = 0; c < C; ++c) sum += expf(xp[(long long)c * HW] / T - m);
+  const float inv = 1.f / sum;
+  for (int c = 0; c < C; ++c) op[(long long)c * HW] = expf(xp[(long long)c * HW] / T - m) * inv;
 }
 
-int softmax_channels(const float* x, int N, int C, int HW, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(softmax_channels_k, dim3((HW + 255) / 256, N), dim3(256), 0, s, x, C, (long long)HW, out);
+int softmax_channels(const float* x, int N, int C, int HW, float* out, hipStream_t s, float T, int use_softmax) {
+  hipLaunchKernelGGL(softmax_channels_k, dim3((HW + 255) / 256, N), dim3(256), 0, s, x, C, (long long)HW, T, use_softmax,
+                     out);
   RLN_LAUNCH_CHECK();
 }
 

@@ -356,6 +356,21 @@ def classifier_op(feat, weight, bias, temperature, use_softmax=True):
     feat = feat.float().contiguous()
     n, c, h, w = feat.shape
     k = weight.shape[0]
+    ks = int(weight.shape[-1]) if weight.dim() == 4 else 1
+    if ks != 1:
+        # finalConv with kernel_size != 1 (tiramisu.py:113-115; FCDenseNet57(n_classes, kernel_size)): the k x k implicit
+        # GEMM with padding k // 2, then / T and the channel softmax
+        if weight.shape[-1] != weight.shape[-2] or ks not in (3, 7):
+            raise RuntimeError(f"classifier kernel_size {tuple(weight.shape[-2:])}: 1, 3 and 7 are built on the HIP path")
+        wt = weight.detach().float().contiguous()
+        bt = bias.detach().float().contiguous()
+        logits = torch.empty((n, k, h, w), dtype=torch.float32, device=feat.device)
+        _lib.check(L.rln_op_conv_act(_ptr(feat), n, c, h, w, _ptr(wt), _ptr(bt), k, ks, 0, 0.0, _ptr(logits), None, None, 0,
+                                     _stream()), "rln_op_conv_act")
+        out = torch.empty_like(logits)
+        _lib.check(L.rln_op_scaled_softmax(_ptr(logits), n, k, h * w, float(temperature), int(use_softmax), _ptr(out),
+                                           _stream()), "rln_op_scaled_softmax")
+        return out
     wt = weight.detach().reshape(k, c).float().contiguous()
     bt = bias.detach().float().contiguous()
     out = torch.empty((n, k, h, w), dtype=torch.float32, device=feat.device)

@@ -120,9 +120,6 @@ class FCDenseNetClassifier(nn.Module):
         self.T = temperature
 
     def forward(self, x, useSoftmax=True):
-        if tuple(self.finalConv.kernel_size) != (1, 1):
-            raise RuntimeError("only the kernel_size=1 classifier (what every reference script builds) runs on the "
-                               "HIP path")
         if torch.is_grad_enabled() and (x.requires_grad or (self.training and self.finalConv.weight.requires_grad)):
             raise RuntimeError(
                 "FCDenseNetClassifier.forward is inference-only on the HIP path: call it under torch.no_grad() / in eval "
@@ -151,10 +148,18 @@ class FCDenseNet(nn.Module, EngineOwner):
         return out
 
     def forward(self, x):
+        wide = tuple(self.classifier.finalConv.kernel_size) != (1, 1)
         if self.training and torch.is_grad_enabled():  # differentiable (comparison.py-style user training code)
+            if wide:
+                raise RuntimeError("a classifier with kernel_size != 1 is inference-only on the HIP path (the fused "
+                                   "backward covers the 1x1 classifier every reference script builds)")
             return ForwardFn.apply(self, x, None, None, *self._rln_params_in_arena_order())
         eng = self._rln_sync()
         with torch.no_grad():
+            if wide:  # fused feature extractor, then the k x k classifier kernel (tiramisu.py:113-115)
+                _, feat = eng.forward(x, training=self.training, with_backward=False, want_probs=False, want_feat=True)
+                return classifier_op(feat, self.classifier.finalConv.weight, self.classifier.finalConv.bias,
+                                     self.classifier.T)
             probs, _ = eng.forward(x, training=self.training, with_backward=False)
         return probs
 

@@ -68,8 +68,9 @@ class EngineOwner:
         cl = getattr(self, "classifier", None)
         n_cls = cl.finalConv.out_channels if cl is not None else 1
         temp = cl.T if cl is not None else 0.05
-        if cl is not None and tuple(cl.finalConv.kernel_size) != (1, 1):
-            raise RuntimeError("only kernel_size=1 classifiers run on the HIP path")
+        # a classifier whose finalConv is not 1x1 (FCDenseNet57(n_classes, kernel_size)) runs as its own k x k kernel behind
+        # the fused feature extractor (inference); the fused net then carries a 1x1 stand-in that is never read
+        self.__dict__["_rln_wide_classifier"] = cl is not None and tuple(cl.finalConv.kernel_size) != (1, 1)
         return NetSpec(in_channels=fe.in_channels, down_blocks=tuple(fe.down_blocks), up_blocks=tuple(fe.up_blocks),
                        bottleneck_layers=fe.bottleneck_layers, growth_rate=fe.growth_rate,
                        out_chans_first_conv=fe.out_chans_first_conv, n_classes=n_cls, temperature=float(temp))
@@ -105,6 +106,8 @@ class EngineOwner:
         names = []
         for m in eng.metas:
             src = current.get(m.name)
+            if self.__dict__.get("_rln_wide_classifier") and m.name.startswith("classifier."):
+                continue  # the k x k classifier keeps its own tensors (its kernel reads them directly)
             if src is None:
                 if m.name.startswith("classifier."):  # feature extractor used alone: dummy classifier stays zero
                     continue

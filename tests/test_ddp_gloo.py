@@ -148,3 +148,68 @@ def test_two_rank_train_stepper_real_segments(tmp_path):
     O.adamw_step(p, (r[0]["own"] + r[1]["own"]) * 0.5, torch.zeros_like(p), torch.zeros_like(p), 1, 1e-3,
                  weight_decay=1e-4)
     assert torch.allclose(r[0]["params"], p, rtol=0, atol=2e-7)                       # (iii)
+
+
+# ---- the module path (what Lightning drives): loss.backward() -> EngineOwner._rln_backward_into_fresh_arena ----------
+# Same stand-in idea: the owner method is run as it is; the engine underneath replays recorded per-rank gradient arenas
+# segment by segment into whatever buffer is bound.  Checked: autograd receives the MEAN over ranks (torch-DDP
+# semantics: d(loss) is scaled by 1/world before the summing all-reduce), as views of one fresh flat buffer, the engine's
+# own arena is bound again afterwards, and the device-side loss scale reaches every segment.
+class _BindableEngine:
+    def __init__(self, real, recorded):
+        self.seg_ranges, self.n_seg, self.n_param, self.metas = real.seg_ranges, real.n_seg, real.n_param, real.metas
+        self.params = real.params.clone()
+        self.grads = torch.zeros(real.n_param)
+        self.bound = self.grads
+        self.recorded = recorded
+        self.calls = []
+
+    def bind_grads(self, flat):
+        self.bound = self.grads if flat is None else flat
+
+    def backward(self, loss_scale, sb=0, se=None, loss_scale_dev=None):
+        se = self.n_seg if se is None else se
+        scale = loss_scale * (float(loss_scale_dev) if loss_scale_dev is not None else 1.0)
+        for s in range(sb, se):
+            b, e = self.seg_ranges[s]
+            self.bound[b:e] = self.recorded[b:e] * scale
+        self.calls.append((sb, se))
+
+
+def _module_path_worker(rank, world, port, out_dir):
+    from sim2real_lane_segment_amd.owner import EngineOwner
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    real = Engine(NetSpec(n_classes=4), device="cpu")
+    rec = torch.arange(real.n_param, dtype=torch.float32) * 1e-4 + (rank + 1)
+    eng = _BindableEngine(real, rec)
+
+    class Owner(EngineOwner):
+        pass
+
+    own = Owner()
+    own._rln_param_set = {m.name for m in real.metas if m.kind == _lib.T_PARAM}
+    own._rln_reducer = BucketedGradReducer(eng.grads, eng.seg_ranges, 4)
+    g_loss = torch.tensor(0.5)
+    grads = own._rln_backward_into_fresh_arena(eng, g_loss)
+    base = grads[0]._base if grads[0]._base is not None else grads[0]
+    flat_ok = all(g._base is base or g is base for g in grads) and base.numel() == real.n_param
+    torch.save({"flat": base.clone(), "flat_ok": bool(flat_ok), "rebound": eng.bound is eng.grads,
+                "own_untouched": bool((eng.grads == 0).all()), "calls": eng.calls, "rec": rec},
+               os.path.join(out_dir, f"m{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_module_path_overlapped_allreduce(tmp_path):
+    port = _free_port()
+    mp.spawn(_module_path_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), f"m{k}.pt"), weights_only=True) for k in range(2)]
+    mean = 0.5 * (r[0]["rec"] + r[1]["rec"]) / 2          # d(loss) = 0.5 on both ranks, mean over the 2 ranks
+    for k in range(2):
+        assert r[k]["flat_ok"] and r[k]["rebound"] and r[k]["own_untouched"]
+        assert torch.allclose(r[k]["flat"], mean, rtol=1e-6, atol=1e-9)
+        assert len(r[k]["calls"]) >= 2 and r[k]["calls"][0][0] == 0          # bucket by bucket, not one backward
+        assert all(a[1] == b[0] for a, b in zip(r[k]["calls"][:-1], r[k]["calls"][1:]))

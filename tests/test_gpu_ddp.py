@@ -76,3 +76,76 @@ def test_two_gpu_ranks_train_stepper(tmp_path):
         err = (r[k]["reduced"] / 2 - mean).norm() / mean.norm()
         assert err < 1e-6, f"rank {k}: averaged gradients differ from the mean of the single-rank arenas ({err:.2e})"
     assert torch.equal(r[0]["params"], r[1]["params"])
+
+
+MODULE_WORKER = textwrap.dedent(r'''
+    import os, sys, torch, torch.distributed as dist
+    sys.path.insert(0, sys.argv[1]); out_dir = sys.argv[2]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", device_id=dev)
+    from sim2real_lane_segment_amd.synthetic import make_batch
+    from sim2real_lane_segment_amd.trainingModules.SimpleTrain import SimpleTrainModule
+    torch.manual_seed(0)
+    model = SimpleTrainModule(num_cls=4).to(dev).train()
+    ref = SimpleTrainModule(num_cls=4).to(dev).train()
+    ref.load_state_dict(model.state_dict())
+    x, y = make_batch(4, 64, 96, seed=42, first_index=rank * 4, device=dev)
+    # un-reduced gradients of this rank's batch
+    l0 = ref.training_step((x, y), 0, seed=5)
+    l0.backward()
+    own = torch.cat([p.grad.reshape(-1) for p in ref._rln_params_in_arena_order()]).clone()
+    # the module path with the overlapped all-reduce inside loss.backward()
+    red = model.enable_grad_allreduce(n_buckets=4, force_collectives=(world == 1))
+    (opt,), _ = model.configure_optimizers()
+    l1 = model.training_step((x, y), 0, seed=5)
+    (2.0 * l1).backward()                       # a non-unit d(loss) reaches the kernels from the device (2: exact)
+    got = torch.cat([p.grad.reshape(-1) for p in model._rln_params_in_arena_order()]).clone()
+    opt.step()
+    torch.cuda.synchronize()
+    torch.save({"own": own.cpu(), "got": got.cpu(), "buckets": len(red.buckets),
+                "params": torch.cat([p.detach().reshape(-1) for p in model._rln_params_in_arena_order()]).cpu()},
+               os.path.join(out_dir, f"m{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+''')
+
+
+def _run_module_workers(tmp_path, world):
+    script = tmp_path / "ddp_module_worker.py"
+    script.write_text(MODULE_WORKER)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, str(script), REPO, str(tmp_path)], env=env))
+    codes = [p.wait(timeout=600) for p in procs]
+    assert codes == [0] * world
+    return [torch.load(os.path.join(str(tmp_path), f"m{k}.pt"), weights_only=True) for k in range(world)]
+
+
+@pytest.mark.gpu
+def test_module_path_allreduce_one_rank_plumbing(tmp_path):
+    """One RCCL rank with the collectives forced on: loss.backward() runs its segments bucket by bucket with an
+    all-reduce of every finished slice on the side stream; with one rank the result must equal the plain backward
+    (times the d(loss) = 2 handed in from the device: a power of two commutes with every rounding), bit for bit."""
+    r = _run_module_workers(tmp_path, 1)[0]
+    assert r["buckets"] >= 2
+    assert torch.equal(r["got"], 2.0 * r["own"])
+
+
+@pytest.mark.gpu
+def test_module_path_allreduce_two_ranks(tmp_path):
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    r = _run_module_workers(tmp_path, 2)
+    mean = 2.0 * (r[0]["own"] + r[1]["own"]) / 2
+    for k in range(2):
+        err = (r[k]["got"] - mean).norm() / mean.norm()
+        assert err < 1e-6, f"rank {k}: module-path gradients differ from the mean over ranks ({err:.2e})"
+    assert torch.equal(r[0]["params"], r[1]["params"])
