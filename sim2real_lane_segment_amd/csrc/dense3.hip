@@ -421,7 +421,7 @@ __global__ __launch_bounds__(768, 3) void d3_fwd_k(const D3Fwd p) {
 
 bool d3_fwd_supported(const D3Fwd& p) {
   if (p.Cout > 16 || p.Cout < 1 || p.Cin < 1) return false;
-  if ((p.W & 3) || p.W < 40 || p.H < 4) return false;
+  if ((p.W & 3) || p.W < 20 || p.H < 4) return false;  // (rows of 20: the 15x20 level, whole samples per tile)
   if ((p.cs & 3) || (p.ns & 3) || (p.out_cs & 3) || (p.out_ns & 3)) return false;
   const uintptr_t amask = p.st == ST_BF16 ? 7 : 15;  // a quad of elements per load / store
   if ((reinterpret_cast<uintptr_t>(p.S) & amask) || (reinterpret_cast<uintptr_t>(p.out) & amask)) return false;
@@ -439,7 +439,7 @@ void d3_fwd_pick_tile(int H, int W, int np, int* th, int* tw, int* rg, int st) {
     *tw = W;
     const int cap = np >= 3 ? 320 : 640;  // pixels per tile (LDS: two image buffers)
     int t = cap / W;
-    t = t >= 8 ? 8 : (t >= 4 ? 4 : (t >= 2 ? 2 : 1));
+    t = t >= 16 && W < 40 ? 16 : (t >= 8 ? 8 : (t >= 4 ? 4 : (t >= 2 ? 2 : 1)));  // narrow levels: whole samples per tile
     *th = t;
   } else {
     *tw = 80;
@@ -549,6 +549,14 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
     const int ch = cb + (tid & 15);
     abtab[tid] = ch < p.Cin ? (tid < 16 ? p.pa[ch] : p.pb[ch]) : 0.f;
   }
+  if (p.tiles_x == 1) {  // full-width tiles (the 15x20 level: a whole sample per tile): zero padding columns, written once
+    for (int i = tid; i < 2 * NP * rows * 2; i += 768) {
+      const int side = i & 1, r = (i >> 1) % rows, bp = (i >> 1) / rows;  // bp = buffer * NP + part
+      uint4* z = reinterpret_cast<uint4*>(zbuf + bp * PLZ + (r * P + (side ? p.tw + 1 : 0)) * 32);
+      z[0] = make_uint4(0u, 0u, 0u, 0u);
+      z[1] = make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
 
   f32x4 acc[9];
 #pragma unroll
@@ -591,7 +599,7 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
       u_o = hu & 3;  // channel quad
       h_side = (hu >> 2) & 1;
       u_r = hu >> 3;
-      u_ex = u_r < rows;
+      u_ex = u_r < rows && p.tiles_x > 1;  // full-width tiles: both halo columns lie outside the picture (zeroed below)
       u_lds = ((u_ex ? u_r : 0) * P + (h_side ? p.tw + 1 : 0)) * 32 + u_o * 8;
     }
     // Every thread issues the SAME 8 dwordx4 loads per tile from (kind base) + choff[cc] + per-tile pixel offset: no
@@ -823,7 +831,7 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
 
 bool d3_wgrad_supported(const D3Wgrad& p) {
   if (p.Cout < 1 || p.Cout > 16 || p.Cin < 1) return false;
-  if ((p.W % 40) != 0 || p.H < 4) return false;
+  if (((p.W % 40) != 0 && !(p.W == 20 && p.H <= 16)) || p.H < 4) return false;  // 15x20 level: one sample per tile
   if ((p.cs & 3) || (p.ns & 3)) return false;
   const uintptr_t amask = p.st == ST_BF16 ? 7 : 15;
   if ((reinterpret_cast<uintptr_t>(p.S) & amask) || (reinterpret_cast<uintptr_t>(p.dY) & amask)) return false;
@@ -831,7 +839,10 @@ bool d3_wgrad_supported(const D3Wgrad& p) {
 }
 
 void d3_wgrad_plan(int H, int W, int N, int Cin, D3Wgrad* p) {
-  if (W % 80 == 0) {  // 320-pixel tiles: 4 x 80, or 8 x 40 where a row is not a multiple of 80
+  if (W == 20) {  // 16 x 20: the whole 15 x 20 sample (rows past H carry zero gradient)
+    p->th = 16;
+    p->tw = 20;
+  } else if (W % 80 == 0) {  // 320-pixel tiles: 4 x 80, or 8 x 40 where a row is not a multiple of 80
     p->th = 4;
     p->tw = 80;
   } else {
@@ -870,8 +881,14 @@ static int d3_wgrad_launch_t(const D3Wgrad& p, hipStream_t s) {
 }
 
 int d3_wgrad_launch(const D3Wgrad& p, int np, int dt, hipStream_t s) {
-  if (!d3_wgrad_supported(p) || p.th * p.tw != 320 || (p.tw != 80 && p.tw != 40) || p.rg != 2) return -4;
-  if ((p.th + 2) * 8 > 96 || p.th * (p.tw / 4) * 2 > 160) return -4;  // halo / dY unit budgets of the producer threads
+  if (!d3_wgrad_supported(p) || p.th * p.tw != 320 || (p.tw != 80 && p.tw != 40 && p.tw != 20) || p.rg != 2) return -4;
+  // halo / dY / z unit budgets of the producer threads (full-width tiles have no halo units)
+  if ((p.tiles_x > 1 && (p.th + 2) * 8 > 96) || p.th * (p.tw / 4) * 2 > 160) return -4;
+  if (p.tw == 20 && p.tiles_x != 1) return -4;
+  {
+    const int nq = p.tw / 4, nqg = (nq + 1) / 2, nrg = (p.th + 2 + 1) / 2;
+    if (8 * nrg * nqg > 256) return -4;
+  }
   if (p.st == ST_BF16) {
     if (np != 1 || dt != D3_BF16) return -4;
     return d3_wgrad_launch_t<1, D3_BF16, ST_BF16>(p, s);
@@ -925,6 +942,14 @@ __global__ __launch_bounds__(512, 2) void d3_pull_k(const D3Pull p) {
   for (int i = tid; i < Cpad; i += 512) {
     mtab[i * 2 + 0] = p.mean[min(i, p.C - 1)];
     mtab[i * 2 + 1] = p.invstd[min(i, p.C - 1)];
+  }
+  if (p.tiles_x == 1) {  // full-width tiles (rows of 20 / 40 pixels): the two halo columns are zero padding, written once
+    for (int i = tid; i < p.nl * NP * rows * 2; i += 512) {
+      const int side = i & 1, r = (i >> 1) % rows, jp = (i >> 1) / rows;  // jp = layer * NP + part
+      uint4* z = reinterpret_cast<uint4*>(smem + jp * PLANE + (r * P + (side ? p.tw + 1 : 0)) * 32);
+      z[0] = make_uint4(0u, 0u, 0u, 0u);
+      z[1] = make_uint4(0u, 0u, 0u, 0u);
+    }
   }
 
   const int tiles = p.tiles_x * p.tiles_y;
@@ -983,7 +1008,7 @@ __global__ __launch_bounds__(512, 2) void d3_pull_k(const D3Pull p) {
         const int j = min(hu / hul, p.nl - 1);
         const int h2 = hu - j * hul;
         const int cp = h2 & 7, side = (h2 >> 3) & 1, r = h2 >> 4;
-        const bool ex = hu < p.nl * hul;
+        const bool ex = hu < p.nl * hul && p.tiles_x > 1;  // full-width tiles: the halo columns are padding (zeroed once)
         const int iy = gy0 - 1 + r, ix = side ? gx0 + p.tw : gx0 - 1;
         const bool ok = ex && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
         const SP<ST> src = SP<ST>(p.dY[j]) + (((long long)n * p.Cout) * p.cs + (ok ? iy * p.W + ix : 0));
@@ -1211,10 +1236,12 @@ static size_t d3_pull_lds(const D3Pull& p, int np) {
 
 bool d3_pull_supported(const D3Pull& p, int np) {
   if (p.nl < 1 || p.nl > D3_LMAX || p.Cout < 1 || p.Cout > 16 || p.C < 1) return false;
-  if (p.nl * 8 * ((p.th + 2 + 3) / 4) * (p.tw / 4) > 1024 || p.nl * (p.th + 2) * 16 > 512) return false;  // staging rounds
+  if (p.nl * 8 * ((p.th + 2 + 3) / 4) * (p.tw / 4) > 1024) return false;                  // staging rounds
+  if (p.tiles_x > 1 && p.nl * (p.th + 2) * 16 > 512) return false;                         // halo units
   if (p.th * p.tw != 160 || d3_pull_lds(p, np) > 160 * 1024) return false;
   if ((p.W & 3) || (p.cs & 3) || (p.s_ns & 3)) return false;
-  if (!(p.W % 80 == 0 || p.W == 40)) return false;
+  if (!(p.W % 80 == 0 || p.W == 40 || p.W == 20)) return false;
+  if ((p.W == 40 || p.W == 20) && p.tiles_x != 1) return false;
   const uintptr_t amask = p.st == ST_BF16 ? 7 : 15;
   if ((reinterpret_cast<uintptr_t>(p.S) & amask) || (reinterpret_cast<uintptr_t>(p.G) & 15)) return false;
   for (int j = 0; j < p.nl; ++j)
@@ -1227,6 +1254,9 @@ void d3_pull_pick_tile(int H, int W, int* th, int* tw) {
   if (W % 80 == 0) {
     *tw = 80;
     *th = 2;
+  } else if (W == 20) {
+    *tw = 20;
+    *th = 8;
   } else {
     *tw = 40;
     *th = 4;

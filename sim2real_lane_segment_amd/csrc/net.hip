@@ -981,6 +981,20 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
     q.stat_partial = p.stat_partial;
     q.ksplit = 1;
     q.st = dl.st;
+    // Small levels (one tile does not fill the chip): the input-channel loop is split over blocks exactly like the
+    // exact-fp32 family does it -- raw partial sums to scratch, bias / Dropout2d scale / statistics in the finish pass
+    // (only where one tile per sample leaves the chip empty: rows of < 40 pixels; the 30x40 level is faster unsplit)
+    const int sp3 = (dl.st == ST_F32 && dl.W < 40) ? dense_fwd_split(dl.H * dl.W, o.cin) : 1;
+    if (sp3 > 1) {
+      q.ksplit = sp3;
+      q.split_stride = (long long)N * o.cout * dl.H * dl.W;
+      q.out = c->fsplit;
+      q.out_ns = (long long)o.cout * dl.H * dl.W;
+      q.out_cs = dl.H * dl.W;
+      q.bias = nullptr;
+      q.nscale = nullptr;
+      q.stat_partial = nullptr;
+    }
     if (d3_fwd_supported(q)) {
       d3_fwd_pick_tile(q.H, q.W, c->d3_fwd_np, &q.th, &q.tw, &q.rg, q.st);
       q.tiles_y = (q.H + q.th - 1) / q.th;
@@ -996,6 +1010,14 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
       // family below, like a geometry d3_fwd_supported() rejects; nothing was launched in that case
       if (e3 != 0 && (e3 != RLN_ERR_UNSUPPORTED || dl.st != ST_F32))
         return fail(e3, "d3_fwd_launch failed with %d (op %zu)", e3, k);
+      if (e3 == 0 && sp3 > 1) {
+        long long nblk = 0;
+        ProfScope ps(c, PC_D3_FWD, 0, 0, s);
+        RLN_TRY(splitk_finish(c->fsplit, sp3, q.split_stride, N, o.cout, dl.H * dl.W, p.bias, p.nscale, p.out, p.out_ns,
+                              p.stat_partial, &nblk, s));
+        if (training) RLN_TRY(finalize_stats(c, o.dst_level, o.out_off, o.cout, nblk, s, (long long)k));
+        return 0;
+      }
       if (e3 == 0) {
         if (training)
           RLN_TRY(finalize_stats(c, o.dst_level, o.out_off, o.cout, (long long)N * q.tiles_x * q.tiles_y, s,
@@ -1387,7 +1409,46 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
       w.v_ns = (long long)lv.C * plane;
       w.pa = c->ab + o.bn.ab;
       w.pb = c->ab + c->n_ab + o.bn.ab;
-      if (fuse_tail) {
+      bool d3w = false;
+      if (fuse_tail && c->d3_bwd_np > 0 && o.cout <= 16) {  // transposed-read 16-bit MFMA kernel where it covers the level
+        D3Wgrad g;
+        memset(&g, 0, sizeof(g));
+        g.S = w.v;
+        g.ns = w.v_ns;
+        g.cs = (int)plane;
+        g.H = lv.H;
+        g.W = lv.W;
+        g.Cin = o.cin;
+        g.pa = w.pa;
+        g.pb = w.pb;
+        g.dY = c->dY;
+        g.Cout = o.cout;
+        g.N = N;
+        g.partial = c->wpartial;
+        g.st = lv.st;
+        if (d3_wgrad_supported(g)) {
+          d3_wgrad_plan(lv.H, lv.W, N, o.cin, &g);
+          {
+            const double wflops = 2.0 * o.cout * o.cin * 9.0 * plane * N;
+            const double wbytes = (double)st_bytes(lv.st) * N * ((double)o.cout + o.cin) * plane;
+            ProfScope ps(c, PC_D3_WGRAD, wflops, wbytes, s);
+            RLN_TRY(d3_wgrad_launch(g, wgrad_parts(c, (long long)N * lv.H * lv.W), c->d3_bwd_dt, s));
+          }
+          tail.w_src = c->wpartial;
+          tail.w_rows = g.nranges;
+          tail.w_len = w.wsize;
+          tail.w_dst = c->grads + o.conv.w;
+          tail.b_src = c->bpartial;
+          tail.b_rows = rows;
+          tail.b_len = o.cout;
+          tail.b_dst = c->grads + o.conv.b;
+          ProfScope pst(c, PC_REDUCE, 0, 4.0 * (g.nranges + 1) * w.wsize, s);
+          RLN_TRY(dense_tail(tail, s));
+          d3w = true;
+        }
+      }
+      if (d3w) {
+      } else if (fuse_tail) {
         long long wrows = 0;
         RLN_TRY(run_wgrad(c, WG_DENSE3, w, o.cout, o.cin, o.conv.w, ws, &wrows));
         tail.w_src = c->wpartial;
