@@ -543,6 +543,8 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
         wp_max = std::max(wp_max, (size_t)nch * o.cout * o.cin * 9);
         if (c->d3_bwd_np > 0 && o.type == OP_DENSE) {
           D3Wgrad g;
+          memset(&g, 0, sizeof(g));
+          g.st = lst[o.dst_level];
           d3_wgrad_plan(Hd, Wd, n, o.cin, &g);
           wp_max = std::max(wp_max, (size_t)g.nranges * o.cout * o.cin * 9);
         }
