@@ -1926,7 +1926,7 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
   // round trip: 113 us per launch whatever the layer count) and the form loses 1.1 ms per step against the per-layer
   // kernel; it stays available to diagnostic builds (RLN_PULL_NEW).
   const bool pull_new = gr == 16 && (C0 % 16) == 0 && L - 1 <= D3_LMAX && rln_env("RLN_PULL_NEW") != nullptr;
-  auto pull_range = [&](int ch_lo, int C, int i_lo, int i_hi, int acc_lo, int acc_hi) -> int {
+  auto pull_range = [&](int ch_lo, int C, int i_lo, int i_hi, int acc_lo, int acc_hi, long long* defer_rows) -> int {
     // input channels [ch_lo, ch_lo + C) of the block (relative to its first input channel) from layers i_hi .. i_lo
     D3Pull g = q;
     D3PullFin f;
@@ -1965,6 +1965,10 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
     f.C = C;
     f.Cpad = ((C + 15) / 16) * 16;
     f.rows = d3_pull_nsub(g) * d3_pull_blocks(g);
+    if (defer_rows) {  // one layer, C a multiple of 16: the partial rows have dense_tail's [rows][C][2] layout
+      *defer_rows = f.rows;
+      return 0;
+    }
     f.partial = c->stat_partial;
     f.S1 = c->S1 + lv.stat_off + first.in_off + ch_lo;
     f.S2 = c->S2 + lv.stat_off + first.in_off + ch_lo;
@@ -1972,6 +1976,13 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
     RLN_TRY(d3_pull_finalize(f, s));
     return 0;
   };
+  // The per-layer data gradient of the block's own channels as a one-layer pull launch (16-bit MFMA family instead of
+  // the exact-fp32 kernel, which is matrix-pipe bound: profiles/r03_pmc_sq_f32.json, dgrad_loop_k: 49 % of the MFMA
+  // cycles at 1/16 of the 16-bit rate).  Measured on MI355X, batch 64: 25.0 -> 25.4 ms per step -- a pull launch over
+  // few channel groups pays a load round trip per tile (30 tiles per block), and prefetching the next tile's dY across
+  // the work items does not hide it (vmcnt retires in order: the items' own S loads wait for the older prefetch too;
+  // 25.6 ms).  Kept for diagnostic builds (RLN_LAYER_PULL).
+  const bool layer_pull = gr == 16 && (C0 % 16) == 0 && rln_env("RLN_LAYER_PULL") != nullptr;
 
   for (int j = L - 1; j >= 0; --j) {
     const Op& o = c->ops[(size_t)k0 + j];
@@ -1981,7 +1992,7 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
     if (pull_new && j < L - 1) {  // G[group j] += contributions of layers j+1 .. L-1 (all finalised by now)
       const int lo = C0 + gr * j;
       const int alo = std::min(std::max(last_op.acc_lo - lo, 0), gr), ahi = std::min(std::max(last_op.acc_hi - lo, 0), gr);
-      RLN_TRY(pull_range(lo, gr, j + 1, L - 1, alo, ahi));
+      RLN_TRY(pull_range(lo, gr, j + 1, L - 1, alo, ahi, nullptr));
     }
     RLN_TRY(finalize_grad_range(c, o.dst_level, o.out_off, o.cout, nscale, &rows, s, dYj));
     // the layer's three small reductions (bias rows, weight slabs, BatchNorm-backward sums of its new-channel data
@@ -2052,7 +2063,19 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
       }
     }
     const int Jn = pull_new ? 0 : o.cin - C0;  // new channels this layer consumes (per-layer form only)
-    if (Jn > 0) {
+    if (Jn > 0 && layer_pull && use_tail) {
+      long long prow = 0;
+      const int64_t so = lv.stat_off + o.in_off + C0;
+      RLN_TRY(pull_range(C0, Jn, j, j, std::max(0, o.acc_lo - C0), std::max(0, o.acc_hi - C0), &prow));
+      tail.bn_partial = c->stat_partial;
+      tail.bn_rows = prow;
+      tail.J = Jn;
+      tail.gamma = c->params + o.bn.gamma + C0;
+      tail.dgamma = c->grads + o.bn.gamma + C0;
+      tail.dbeta = c->grads + o.bn.beta + C0;
+      tail.S1 = c->S1 + so;
+      tail.S2 = c->S2 + so;
+    } else if (Jn > 0) {
       IgemmParams p;
       memset(&p, 0, sizeof(p));
       p.in = dYj;
