@@ -29,7 +29,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: dense fp
 PEAK_16BIT_MFMA_TFLOPS = 2500.0  # dense bf16 / f16 MFMA peak (same guide; not the 2:1-sparsity figure)
 PEAK_HBM_GBS = 8000.0
 TRAIN_FLOPS_PER_IMAGE = 47_718_689_280  # 3 x 15,906,229,760
-PMC_SUMMARY = "r02_pmc_traffic.json"     # profiles/: FETCH_SIZE / WRITE_SIZE passes of this same command
+PMC_SUMMARY = "r03_pmc_traffic_f32.json"    # profiles/: FETCH_SIZE / WRITE_SIZE passes of this same command
 PMC_SUMMARY_BF16 = "r03_pmc_traffic_bf16.json"
 
 # kernel-name prefixes of each profiled class in the rocprofv3 --pmc summary

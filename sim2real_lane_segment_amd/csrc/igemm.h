@@ -54,7 +54,17 @@ struct IgemmParams {
   int dbg;             // timing ablations only (RLN_DBG): 1 skip global loads, 2 skip LDS commit, 4 skip MFMA, 16 stamps, 32 no XCD remap
   unsigned long long* dbg_out;  // [8] phase cycle sums (diagnostic build path only)
   int st;              // dgrad_loop_launch only: storage element type of `in` (dY) and S (storage.h); 0 = fp32 elsewhere
+  // Sample packing for levels much smaller than a tile (7x10, 3x5 ...): pk_sx > 1 samples sit side by side in one
+  // VIRTUAL image of width pk_sx * (pk_w + 1) - 1, separated by one column that is zero AFTER the activation (= the
+  // convolution's own padding), so a 32-wide tile carries pk_sx samples instead of one.  The kernel then runs over
+  // ceil(pk_n / pk_sx) virtual samples; GH/GW/Hin/Win describe the virtual image, pk_w / pk_n the real row width and
+  // sample count.  Only the staging and epilogue address maps know about it: per output pixel the contraction and its
+  // order are unchanged, so results are bit-identical to the unpacked launch.  dense forward (scalar staging, raw
+  // split-K epilogue) and dgrad_loop (VEC = false) only.
+  int pk_sx, pk_w, pk_n;
 };
+// samples per virtual image for a level of width w in tiles of width tw (1 = no packing)
+inline int igemm_pack_sx(int h, int w) { return (h <= 8 && w + 1 <= 16) ? 33 / (w + 1) : 1; }
 unsigned long long* igemm_debug_buffer();  // device buffer of 8 counters (allocated on first use)
 
 // which compiled variant
@@ -71,7 +81,7 @@ enum IgemmKind {
   IG_CONVT4 = 9,     // KS3 NT1 PRO_RAW    EPI_STORE   convT forward, all four output-parity classes per block (ncls = 1, TM_ID)
 };
 
-// tile: 0 -> 8x32, 1 -> 16x16
+// tile: 0 -> 8x32, 1 -> 16x16, 5 -> 4x32 (dense forward and dgrad_loop without the 16-byte path only)
 int igemm_launch(IgemmKind kind, int tile, const IgemmParams& p, int N, hipStream_t stream);
 void igemm_tile_dims(IgemmKind kind, int tile, int* th, int* tw);
 int igemm_pick_tile(int gh, int gw);

@@ -56,26 +56,53 @@ struct IgCfg {
 
 // Straight-line MFMA block for one staged 16-channel chunk: every LDS offset is a compile-time constant relative
 // to one per-lane base, so reads shared by several (M-tile, tap) pairs are issued once and carry immediates.
+// first active tap at or after s (NS when none)
+template <unsigned long long MASK, int NS>
+__host__ __device__ constexpr int ig_next_tap(int s) {
+  return (s >= NS) ? NS : (((MASK >> s) & 1ull) ? s : ig_next_tap<MASK, NS>(s + 1));
+}
+
+template <unsigned long long MASK>
+__host__ __device__ constexpr int ig_tap_rank(int s) {  // active taps below s
+  return s <= 0 ? 0 : (int)((MASK >> (s - 1)) & 1ull) + ig_tap_rank<MASK>(s - 1);
+}
+
 template <typename C, int NT, int TW, unsigned long long MASK>
 __device__ __forceinline__ void igemm_compute(const float* __restrict__ zbase, const float* __restrict__ wlane,
                                               f32x4 (&acc)[C::MPW][NT]) {
-  // one 4-channel group per (rolled) iteration keeps the live LDS fragments small; inside, straight-line code
+  // One 4-channel group per (rolled) iteration keeps the live LDS fragments small; inside, straight-line code.  The
+  // fragments of tap s+1 are read BEFORE the MFMAs of tap s (two register sets, order pinned with sched_barrier): left
+  // to itself the compiler puts each read group next to its use behind an lgkmcnt(0), i.e. ~8 exposed LDS latencies
+  // per 36 MFMAs -- hidden at 2+ waves per SIMD, 1.7x the matrix time when a wave has its SIMD to itself.
+  constexpr int S0 = ig_next_tap<MASK, C::NS>(0);
 #pragma unroll 1
   for (int kg = 0; kg < 4; ++kg) {
     const float* zk = zbase + kg * 4 * C::CHS;
     const float* wk = wlane + kg * C::NS * NT * 64;
+    float bw[2][NT], av[2][C::MPW];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bw[0][nt] = wk[(S0 * NT + nt) * 64];
+#pragma unroll
+    for (int m = 0; m < C::MPW; ++m) av[0][m] = zk[((m * 16) / TW) * C::PITCH + (m * 16) % TW + C::slot_off(S0)];
 #pragma unroll
     for (int s = 0; s < C::NS; ++s) {
       if (!((MASK >> s) & 1ull)) continue;
-      float bw[NT];
+      const int cur = ig_tap_rank<MASK>(s) & 1;
+      const int s1 = ig_next_tap<MASK, C::NS>(s + 1);
+      if (s1 < C::NS) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bw[nt] = wk[(s * NT + nt) * 64];
+        for (int nt = 0; nt < NT; ++nt) bw[cur ^ 1][nt] = wk[(s1 * NT + nt) * 64];
+#pragma unroll
+        for (int m = 0; m < C::MPW; ++m)
+          av[cur ^ 1][m] = zk[((m * 16) / TW) * C::PITCH + (m * 16) % TW + C::slot_off(s1)];
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int m = 0; m < C::MPW; ++m) {
-        const float a = zk[((m * 16) / TW) * C::PITCH + (m * 16) % TW + C::slot_off(s)];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mfma16(a, bw[nt], acc[m][nt]);
+        for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mfma16(av[cur][m], bw[cur][nt], acc[m][nt]);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
@@ -187,7 +214,14 @@ __global__ __launch_bounds__(256, (((NT == 1 && TH * TW <= 256 && CLS != 2) || (
         ix = gx0 - C::HALO / 2 + col;
       }
       loff[i] = e;
-      if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) goff[i] = iy * p.Win + ix;
+      if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) {
+        if (p.pk_sx > 1) {  // packed samples: virtual column -> (sample in group, column); gap columns stay zero
+          const int sidx = ix / (p.pk_w + 1), x = ix - sidx * (p.pk_w + 1);
+          if (x < p.pk_w && (int)lz * p.pk_sx + sidx < p.pk_n) goff[i] = sidx * (int)p.in_ns + iy * p.pk_w + x;
+        } else {
+          goff[i] = iy * p.Win + ix;
+        }
+      }
     }
   }
   static_assert((MPW * 16) % TW == 0, "a wave's M-tiles must start on a tile row");
@@ -205,7 +239,7 @@ __global__ __launch_bounds__(256, (((NT == 1 && TH * TW <= 256 && CLS != 2) || (
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) accs[cl][m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const float* in_n = p.in + (long long)n * p.in_ns;
+  const float* in_n = p.in + (long long)n * (p.pk_sx > 1 ? p.pk_sx : 1) * p.in_ns;
   const int nchunk = (p.K + 15) >> 4;
 
   // Register-staged software pipeline: the global loads of chunk ch+1 are issued BEFORE the MFMA phase of
@@ -466,7 +500,7 @@ __global__ __launch_bounds__(256, (((NT == 1 && TH * TW <= 256 && CLS != 2) || (
       if constexpr (EPI == EPI_STORE) {
         if (jv) {
           if (p.bias) bias_j = p.bias[j];
-          if (p.nscale) sc = p.nscale[(long long)n * p.J + j];
+          if (p.nscale && p.pk_sx <= 1) sc = p.nscale[(long long)n * p.J + j];
           if (p.cscale) sc *= p.cscale[j];
         }
       } else {
@@ -543,6 +577,27 @@ __global__ __launch_bounds__(256, (((NT == 1 && TH * TW <= 256 && CLS != 2) || (
           const int ty = q / TW, tx = q - ty * TW;
           const int gy = gy0 + ty, gx = gx0 + tx;
           if (!jv || gy >= p.GH) continue;
+          if constexpr (EPI == EPI_STORE && CLS == 0) {
+            if (p.pk_sx > 1) {  // packed samples: every pixel of the group names its own sample
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int vx = gx + r;
+                const int sidx = vx / (p.pk_w + 1), x = vx - sidx * (p.pk_w + 1);
+                const int ns = n * p.pk_sx + sidx;
+                if (vx < p.GW && x < p.pk_w && ns < p.pk_n) {
+                  float t = accc[m][nt][r] + bias_j;
+                  if (p.act == 1) t = fmaxf(t, 0.f);
+                  float scr = p.nscale ? p.nscale[(long long)ns * p.J + j] : 1.f;
+                  if (p.cscale) scr *= p.cscale[j];
+                  t *= scr;
+                  p.out[(long long)ky * p.split_stride + (long long)ns * p.out_ns + (long long)j * p.out_cs + gy * p.pk_w + x] = t;
+                  s1 += t;
+                  s2 += t * t;
+                }
+              }
+              continue;
+            }
+          }
           if constexpr (EPI == EPI_STORE) {
             const int oy = gy * S_ + pyc;
             if (oy >= p.Hout) continue;
@@ -774,6 +829,9 @@ void igemm_tile_dims(IgemmKind kind, int tile, int* th, int* tw) {
   } else if (tile == 4) {  // half-width strips: 3 blocks per CU
     *th = 4;
     *tw = 80;
+  } else if (tile == 5) {  // rows of <= 4 pixels (packed samples of the deepest level)
+    *th = 4;
+    *tw = 32;
   } else if (tile == 0) {
     *th = 8;
     *tw = 32;
@@ -806,6 +864,8 @@ int igemm_launch(IgemmKind kind, int tile, const IgemmParams& p, int N, hipStrea
       if (tile == 2) return launch_v<3, 1, PRO_BNRELU, EPI_STORE, 4, 160, 0, true>(p, N, stream);
       if (tile == 3) return launch_v<3, 1, PRO_BNRELU, EPI_STORE, 8, 80, 0, true>(p, N, stream);
       if (tile == 4) return launch_v<3, 1, PRO_BNRELU, EPI_STORE, 4, 80, 0, true>(p, N, stream);
+      if (tile == 5) return launch_v<3, 1, PRO_BNRELU, EPI_STORE, 4, 32, 0, false>(p, N, stream);
+      if (p.pk_sx > 1) return launch_v<3, 1, PRO_BNRELU, EPI_STORE, 8, 32, 0, false>(p, N, stream);  // scalar staging
       return tile == 0 ? launch_t<3, 1, PRO_BNRELU, EPI_STORE, 8, 32>(p, N, stream)
                        : launch_t<3, 1, PRO_BNRELU, EPI_STORE, 16, 16>(p, N, stream);
     case IG_CONVT4:
@@ -862,7 +922,7 @@ int igemm_launch(IgemmKind kind, int tile, const IgemmParams& p, int N, hipStrea
 // S / G traffic moves as one 16-byte access per lane.  A compile-time switch: as a run-time branch the compiler
 // folds both forms into the scalar one (32 dword loads per lane and step instead of 8 dwordx4).
 template <int TH, int TW, bool VEC, int ST>  // ST: storage element type of dY (p.in) and S; G (p.out) is fp32
-__global__ __launch_bounds__(256, 3) void dgrad_loop_k(const IgemmParams p) {
+__global__ __launch_bounds__(256, VEC ? 3 : 2) void dgrad_loop_k(const IgemmParams p) {  // scalar form: small levels, few blocks
   using C = IgCfg<3, 1, PRO_RAW, EPI_DGRAD, TH, TW>;
   constexpr int MPW = C::MPW;
   constexpr int NWE = C::NWE;  // 9 weight elements per thread and slab
@@ -877,8 +937,9 @@ __global__ __launch_bounds__(256, 3) void dgrad_loop_k(const IgemmParams p) {
   const int n = blockIdx.z;
 
   // ---- stage the dY tile once (clamped unconditional loads + select) ----
+  const int pk = (!VEC && p.pk_sx > 1) ? p.pk_sx : 1;  // samples per virtual image (igemm.h: sample packing)
   {
-    const SP<ST> in_n = SP<ST>(p.in) + (long long)n * p.in_ns;
+    const SP<ST> in_n = SP<ST>(p.in) + (long long)n * pk * p.in_ns;
     const int kmax = p.K - 1;
 #pragma unroll
     for (int i = 0; i < C::NPOS; ++i) {
@@ -886,8 +947,13 @@ __global__ __launch_bounds__(256, 3) void dgrad_loop_k(const IgemmParams p) {
       if (e < C::POS) {
         const int r = e / C::PITCH, col = e - r * C::PITCH;
         const int iy = gy0 - 1 + r, ix = gx0 - 1 + col;
-        const bool ok = iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
-        const int off = ok ? iy * p.Win + ix : 0;
+        bool ok = iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+        int off = ok ? iy * p.Win + ix : 0;
+        if (!VEC && pk > 1 && ok) {
+          const int sidx = ix / (p.pk_w + 1), x = ix - sidx * (p.pk_w + 1);
+          ok = x < p.pk_w && n * pk + sidx < p.pk_n;
+          off = ok ? sidx * (int)p.in_ns + iy * p.pk_w + x : 0;
+        }
         float v[16];
 #pragma unroll
         for (int cc = 0; cc < 16; ++cc) v[cc] = in_n.ld1((long long)min(cc, kmax) * p.in_cs + off);
@@ -934,6 +1000,7 @@ __global__ __launch_bounds__(256, 3) void dgrad_loop_k(const IgemmParams p) {
 
   // ---- per-lane epilogue geometry: M-tile m covers 4 consecutive pixels of one row ----
   int pixoff[MPW];
+  int po[VEC ? 1 : MPW][VEC ? 1 : 4];  // scalar path: element offset of every pixel (clamped to a valid one)
   unsigned vmask = 0;  // 4 validity bits per M-tile
 #pragma unroll
   for (int m = 0; m < MPW; ++m) {
@@ -941,14 +1008,33 @@ __global__ __launch_bounds__(256, 3) void dgrad_loop_k(const IgemmParams p) {
     const int ty = q / TW, tx = q - ty * TW;
     const int gy = gy0 + ty, gx = gx0 + tx;
     unsigned bits = 0;
+    if constexpr (!VEC) {
+      if (pk > 1) {
+        pixoff[m] = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int vx = gx + r;
+          const int sidx = vx / (p.pk_w + 1), x = vx - sidx * (p.pk_w + 1);
+          const bool ok = gy < p.GH && vx < p.GW && x < p.pk_w && n * pk + sidx < p.pk_n;
+          bits |= (ok ? 1u : 0u) << r;
+          po[m][r] = ok ? sidx * (int)p.out_ns + gy * p.pk_w + x : 0;
+        }
+        vmask |= bits << (4 * m);
+        continue;
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) bits |= ((gy < p.GH && gx + r < p.GW) ? 1u : 0u) << r;
     vmask |= bits << (4 * m);
     pixoff[m] = (bits & 1u) ? gy * p.GW + gx : 0;  // clamped to a valid pixel when the whole group is outside
+    if constexpr (!VEC) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) po[m][r] = pixoff[m] + (((bits >> r) & 1u) ? r : 0);
+    }
   }
   constexpr bool vec = VEC;
-  const SP<ST> Sn = SP<ST>(p.S) + (long long)n * p.s_ns;
-  float* Gn = p.out + (long long)n * p.out_ns;
+  const SP<ST> Sn = SP<ST>(p.S) + (long long)n * pk * p.s_ns;
+  float* Gn = p.out + (long long)n * pk * p.out_ns;
   const float* zbase = zl + lk * C::CHS + ((wave * MPW * 16) / TW) * C::PITCH + lj;
   const int nct16 = ((p.J + 15) >> 4) * 16;
   float* red = wl0 + 2 * C::W_FLOATS;  // [4 waves][nct16][2]
@@ -1015,9 +1101,8 @@ __global__ __launch_bounds__(256, 3) void dgrad_loop_k(const IgemmParams p) {
       for (int m = 0; m < MPW; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const bool ok = (vmask >> (4 * m + r)) & 1u;
-          sv[m][r] = Sc.ld1(pixoff[m] + (ok ? r : 0));
-          gv[m][r] = Gc[pixoff[m] + (ok ? r : 0)];
+          sv[m][r] = Sc.ld1(po[m][r]);
+          gv[m][r] = Gc[po[m][r]];
         }
     }
     const float ea = p.ea[jc], eb = p.eb[jc], emean = p.emean[jc], einv = p.einvstd[jc], egam = p.egamma[jc];
@@ -1071,7 +1156,7 @@ __global__ __launch_bounds__(256, 3) void dgrad_loop_k(const IgemmParams p) {
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (jv && ((vmask >> (4 * m + r)) & 1u)) Gc[pixoff[m] + r] = ov[m][r];
+          if (jv && ((vmask >> (4 * m + r)) & 1u)) Gc[po[m][r]] = ov[m][r];
       }
     }
     stamp(t_epi);
@@ -1155,8 +1240,10 @@ int dgrad_loop_launch(int tile, const IgemmParams& p, int N, hipStream_t stream)
     return tile == 0 ? dgrad_loop_launch_t<8, 32, true, ST_BF16>(p, N, stream)
                      : dgrad_loop_launch_t<16, 16, true, ST_BF16>(p, N, stream);
   }
+  if (p.pk_sx > 1 && (p.out_vec || p.s_ns != p.out_ns)) return -1;  // packed samples: scalar path, S and G views congruent
   if (p.out_vec)
     return tile == 0 ? dgrad_loop_launch_t<8, 32, true>(p, N, stream) : dgrad_loop_launch_t<16, 16, true>(p, N, stream);
+  if (tile == 5) return dgrad_loop_launch_t<4, 32, false>(p, N, stream);
   return tile == 0 ? dgrad_loop_launch_t<8, 32, false>(p, N, stream) : dgrad_loop_launch_t<16, 16, false>(p, N, stream);
 }
 

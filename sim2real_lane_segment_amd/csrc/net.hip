@@ -468,6 +468,31 @@ int dense_fwd_split(int hw, int cin) {
   return std::max(1, std::min(want, nchunk));
 }
 
+// Sample packing of the levels much smaller than a tile (igemm.h): rewrites the grid of a dense forward / looped data
+// gradient launch to virtual images of pk samples; returns the number of virtual samples (N when not packed).
+int pack_small_level(IgemmParams& p, int H, int W, int N, int* tile) {
+  const int pk = igemm_pack_sx(H, W);
+  if (pk <= 1 || rln_env("RLN_NO_PACK")) return N;
+  if ((long long)(pk - 1) * std::max(p.in_ns, p.out_ns) >= 0x7fffffffLL) return N;
+  p.pk_sx = pk;
+  p.pk_w = W;
+  p.pk_n = N;
+  p.GH = p.Hin = H;
+  p.GW = p.Win = pk * (W + 1) - 1;
+  *tile = H <= 4 ? 5 : 0;
+  p.tiles_x = p.tiles_y = 1;
+  p.out_vec = 0;
+  return (N + pk - 1) / pk;
+}
+// split-K factor of a packed dense forward: fewer, fuller tiles -> more input-channel ranges (a function of the level
+// only, like dense_fwd_split: a sample's result does not depend on the batch it is in)
+int dense_fwd_split_packed(int hw, int cin) {
+  // one 16-channel chunk per block: with ~1 block per CU a wave has its SIMD to itself and the LDS -> MFMA chain of a
+  // chunk runs at 2.6x its issue time (ablation, tools/abl_small.sh); more, shorter blocks interleave instead
+  (void)hw;
+  return std::max(1, std::min(40, (cin + 15) / 16));
+}
+
 long long wgrad_chunks(long long total_items, int mgroups, int ngroups, int* ipc, int want_blocks = 1024) {
   long long want = (want_blocks + (long long)mgroups * ngroups - 1) / ((long long)mgroups * ngroups);
   if (want < 1) want = 1;
@@ -522,7 +547,8 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
         stat_max = std::max(stat_max, (size_t)n * ((Hd + dth - 1) / dth) * ((Wd + dtw - 1) / dtw) * o.cout * 2);
       }
       if (o.type == OP_DENSE) {
-        const int sp = dense_fwd_split(Hd * Wd, o.cin);
+        const int sp = std::max(dense_fwd_split(Hd * Wd, o.cin),
+                                igemm_pack_sx(Hd, Wd) > 1 ? dense_fwd_split_packed(Hd * Wd, o.cin) : 1);
         if (sp > 1) {
           fs_max = std::max(fs_max, (size_t)sp * n * o.cout * Hd * Wd);
           stat_max = std::max(stat_max, (size_t)n * ((Hd * Wd + 255) / 256) * o.cout * 2);
@@ -1148,10 +1174,13 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
     const int cls = o.type == OP_FIRST ? PC_FIRST_FWD : o.type == OP_DENSE ? PC_DENSE_FWD
                     : o.type == OP_TD  ? PC_TD_FWD : PC_TU_FWD;
     ProfScope ps(c, cls, flops, bytes, s);
-    const int sp = (o.type == OP_DENSE) ? dense_fwd_split(dl.H * dl.W, o.cin) : 1;
+    int sp = (o.type == OP_DENSE) ? dense_fwd_split(dl.H * dl.W, o.cin) : 1;
     if (sp > 1) {  // split-K: raw partial sums to scratch, then bias / dropout scale / statistics in the finish pass
       IgemmParams q = p;
       const int HW = dl.H * dl.W;
+      int qtile = tile;
+      const int ng = (kind == IG_CONV3_BN) ? pack_small_level(q, dl.H, dl.W, N, &qtile) : N;
+      if (q.pk_sx > 1) sp = dense_fwd_split_packed(HW, o.cin);
       q.ksplit = sp;
       q.split_stride = (long long)N * o.cout * HW;
       q.out = c->fsplit;
@@ -1160,8 +1189,8 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
       q.bias = nullptr;
       q.nscale = nullptr;
       q.stat_partial = nullptr;
-      q.out_vec = ((dl.W % 4) == 0 && aligned16(q.out)) ? 1 : 0;
-      RLN_TRY(igemm_launch(kind, tile, q, N, s));
+      q.out_vec = (q.pk_sx <= 1 && (dl.W % 4) == 0 && aligned16(q.out)) ? 1 : 0;
+      RLN_TRY(igemm_launch(kind, qtile, q, ng, s));
       long long nblk = 0;
       RLN_TRY(splitk_finish(c->fsplit, sp, q.split_stride, N, o.cout, HW, p.bias, p.nscale, p.out, p.out_ns,
                             p.stat_partial, &nblk, s));
@@ -1356,25 +1385,26 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
       p.stat_partial = c->stat_partial;
       if (lv.st != ST_F32 && o.cout > 16)
         return fail(RLN_ERR_UNSUPPORTED, "bf16 storage needs growth_rate <= 16");
-      const int tile = igemm_pick_tile(p.GH, p.GW);
+      int tile = igemm_pick_tile(p.GH, p.GW);
       int th, tw;
       igemm_tile_dims(IG_DGRAD3, tile, &th, &tw);
       p.tiles_y = (p.GH + th - 1) / th;
       p.tiles_x = (p.GW + tw - 1) / tw;
       p.out_vec = ((lv.W % 4) == 0 && aligned16(p.out) && aligned16(p.S)) ? 1 : 0;
+      const int ng = (o.cout <= 16 && lv.st == ST_F32) ? pack_small_level(p, lv.H, lv.W, N, &tile) : N;
       {
         const double flops = 2.0 * o.cin * o.cout * 9.0 * plane * N;
         const double bytes = 4.0 * N * plane * ((double)o.cout + 2.0 * o.cin + (double)(o.acc_hi - o.acc_lo));
         ProfScope ps(c, PC_DENSE_DGRAD, flops, bytes, s);
         if (o.cout <= 16) {
-          RLN_TRY(dgrad_loop_launch(tile, p, N, s));
+          RLN_TRY(dgrad_loop_launch(tile, p, ng, s));
         } else {
           RLN_TRY(igemm_launch(IG_DGRAD3, tile, p, N, s));
         }
       }
       if (fuse_tail) {
         tail.bn_partial = c->stat_partial;
-        tail.bn_rows = igemm_stat_blocks(p, N);
+        tail.bn_rows = igemm_stat_blocks(p, ng);
         tail.J = o.cin;
         tail.gamma = c->params + o.bn.gamma;
         tail.dgamma = c->grads + o.bn.gamma;
@@ -1383,7 +1413,7 @@ int bwd_op(rln_ctx* c, size_t k, hipStream_t s) {
         tail.S2 = c->S2 + so;
       } else {
         ProfScope psb(c, PC_BN, 0, 0, s);
-        RLN_TRY(bn_bwd_finalize(c->stat_partial, igemm_stat_blocks(p, N), o.cin,
+        RLN_TRY(bn_bwd_finalize(c->stat_partial, igemm_stat_blocks(p, ng), o.cin,
                                 c->params + o.bn.gamma,
                                 c->grads + o.bn.gamma, c->grads + o.bn.beta, c->S1 + so, c->S2 + so, s));
       }
@@ -2109,26 +2139,27 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
       p.acc_lo = std::max(0, o.acc_lo - C0);
       p.acc_hi = std::max(0, o.acc_hi - C0);
       p.stat_partial = c->stat_partial;
-      const int tile = igemm_pick_tile(p.GH, p.GW);
+      int tile = igemm_pick_tile(p.GH, p.GW);
       int th, tw;
       igemm_tile_dims(IG_DGRAD3, tile, &th, &tw);
       p.tiles_y = (p.GH + th - 1) / th;
       p.tiles_x = (p.GW + tw - 1) / tw;
       p.out_vec = ((lv.W % 4) == 0 && aligned16(p.out) && aligned16(p.S)) ? 1 : 0;
+      const int ng = (o.cout <= 16 && lv.st == ST_F32) ? pack_small_level(p, lv.H, lv.W, N, &tile) : N;
       {
         const double flops = 2.0 * Jn * o.cout * 9.0 * plane * N;
         const double eb = (double)st_bytes(lv.st);  // dY and S in the level's storage type, G in fp32
         const double bytes = (double)N * plane * (eb * o.cout + (eb + 4.0) * Jn + 4.0 * (p.acc_hi - p.acc_lo));
         ProfScope ps(c, PC_DENSE_DGRAD, flops, bytes, s);
         if (o.cout <= 16) {
-          RLN_TRY(dgrad_loop_launch(tile, p, N, s));
+          RLN_TRY(dgrad_loop_launch(tile, p, ng, s));
         } else {
           RLN_TRY(igemm_launch(IG_DGRAD3, tile, p, N, s));
         }
       }
       if (use_tail) {
         tail.bn_partial = c->stat_partial;
-        tail.bn_rows = igemm_stat_blocks(p, N);
+        tail.bn_rows = igemm_stat_blocks(p, ng);
         tail.J = Jn;
         tail.gamma = c->params + o.bn.gamma + C0;
         tail.dgamma = c->grads + o.bn.gamma + C0;
@@ -2137,7 +2168,7 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
         tail.S2 = c->S2 + so;
       } else {
         ProfScope psb(c, PC_BN, 0, 0, s);
-        RLN_TRY(bn_bwd_finalize(c->stat_partial, igemm_stat_blocks(p, N), Jn, c->params + o.bn.gamma + C0,
+        RLN_TRY(bn_bwd_finalize(c->stat_partial, igemm_stat_blocks(p, ng), Jn, c->params + o.bn.gamma + C0,
                                 c->grads + o.bn.gamma + C0, c->grads + o.bn.beta + C0, c->S1 + so, c->S2 + so, s));
       }
     }
