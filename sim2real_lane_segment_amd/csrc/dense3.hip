@@ -275,8 +275,12 @@ __global__ __launch_bounds__(768, 3) void d3_fwd_k(const D3Fwd p) {
     auto bufof = [&](int i) __attribute__((always_inline)) { return smem + ((c_begin + i) & 1) * IMG; };
     // (Measured with bf16 stacks and not kept: four register sets = loads in flight for four iterations, -7 %; 16-byte
     // loads of 8 pixels per lane, +-0; 320-pixel column tiles with one register set and two workgroups per CU, -18 %.
-    // In steady state the kernel moves 4.0 - 4.6 TB/s of its strip pattern; what is left is the fill / drain of the
-    // 7.5 consecutive blocks per CU of a level-0 launch.)
+    // In steady state the kernel moves 4.0 - 4.6 TB/s of its strip pattern.  A persistent form was built and measured
+    // too -- 8 XCDs x 32 blocks, each walking its share of the (sample, tile) order as ONE pipeline of (tile, chunk)
+    // items, so that the next tile's first chunks load under the last MFMAs and the epilogue stores of this one, with
+    // the padding cells and the BN table set up once per CU: parity-green, 4.67 -> 4.62 ms per step at the two large
+    // levels and +0.08 ms at the 30x40 / 15x20 levels (one tile per block there; every cell re-zeroed per tile): the
+    // ~55 us a level-0 launch costs beyond its per-plane rate is NOT block turnover, and the form is not kept.)
     // chunk c_begin+i lives in set i & 1.  Iteration i (consumers multiply chunk i): commit chunk i+1 into the other
     // LDS buffer, refill its register set with chunk i+3.
     Stage RB;

@@ -11,5 +11,6 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --no-cpu-baseline --no-profile --no-secondary --no-module-api --no-inference --steps 20 --warmup 5 --dtype $mode > $OUT/bench.json 2> $OUT/bench.log
 python3 $R/tools/trace_by_grid.py $(ls $OUT/stats/*/*kernel_trace.csv | head -1) 25 $rows > $OUT/by_grid_$mode.txt
+python3 $R/tools/trace_gaps.py $(ls $OUT/stats/*/*kernel_trace.csv | head -1) 25 > $OUT/gaps_$mode.txt
 cp $(ls $OUT/stats/*/*kernel_stats.csv | head -1) $OUT/kernel_stats_$mode.csv
 rm -rf $OUT/stats
