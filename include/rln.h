@@ -112,6 +112,16 @@ int rln_get_storage(const rln_ctx* ctx);
 
 int rln_bind_params(rln_ctx* ctx, float* params, float* grads, float* bn_running, int64_t* num_batches_tracked);
 
+/* rln_set_eval_cache: frozen-model loops (makeDemoVideo.py:15-47, test.py:80-94: model.eval(), then one forward per
+ * frame).  An eval forward (training = 0) normally rebuilds the MFMA weight fragments and the BatchNorm tables folded
+ * from the running statistics on every call, because the optimiser may have changed the arena in between (66 small
+ * launches, 0.36 ms of a 4.7 ms 480x640 frame).  With enable = 1 the next eval forward builds them and the following
+ * ones reuse them until something invalidates them: a training forward, rln_bind_params, rln_set_workspace,
+ * rln_set_dense_arith, rln_set_storage or another rln_set_eval_cache call.  The caller promises not to write the
+ * parameter arena or the running statistics in between (rln_adamw_step / rln_sgd_step take raw pointers: call
+ * rln_set_eval_cache again after them).  Results are bit-identical to the uncached forward.  Default: off. */
+int rln_set_eval_cache(rln_ctx* ctx, int enable);
+
 /* ---- workspace -------------------------------------------------------------------------
  * Activation stacks, gradient stacks, statistics and scratch for a given input geometry.
  * The host allocates (torch caching allocator) and hands the block over. */

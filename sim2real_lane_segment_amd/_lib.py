@@ -84,6 +84,7 @@ _PROTOS = {
     "rln_get_wgrad_parts": (c_int, [c_void_p]),
     "rln_set_storage": (c_int, [c_void_p, c_int]),
     "rln_get_storage": (c_int, [c_void_p]),
+    "rln_set_eval_cache": (c_int, [c_void_p, c_int]),
     "rln_op_convt": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
                              c_int, c_int, c_void_p]),
     "rln_profile_enable": (c_int, [c_void_p, c_int]),

@@ -171,6 +171,9 @@ struct rln_ctx {
   const int64_t* last_y = nullptr;
   int have_train_fwd = 0, have_loss = 0;
   long long prep_done = -1;  // op whose bn_prep already ran with the previous op's bn_finalize
+  int eval_cache_on = 0;     // rln_set_eval_cache
+  int eval_tables_valid = 0; // packed forward weights + folded BN tables are those of the current arena (eval mode)
+  int eval_reuse = 0;        // this forward reuses them
   int loss_mode = 0;      // 0: weighted CE (rln_loss), 1: entropy with gradient reversal (rln_entropy_loss)
   float loss_lamda = 0.f;
   const float* last_scales = nullptr;
@@ -887,6 +890,7 @@ int finalize_stats(rln_ctx* c, int level, int ch_off, int J, long long nblk, hip
 }
 
 int prep_bn(rln_ctx* c, const Op& o, int training, hipStream_t s, long long k = -1) {
+  if (!training && c->eval_reuse) return 0;  // rln_set_eval_cache: the tables of the previous eval forward stand
   if (training && k >= 0 && c->prep_done == k) {  // done together with the previous op's statistics
     c->prep_done = -1;
     return 0;
@@ -2291,6 +2295,7 @@ int rln_tensor_info(const rln_ctx* c, int idx, char* name, int name_cap, int* ki
 }
 
 int rln_set_dense_arith(rln_ctx* c, int fwd_parts, int fwd_dtype, int bwd_parts, int bwd_dtype) {
+  c->eval_tables_valid = 0;
   auto bad = [](int np, int dt) { return np < 0 || np > 3 || dt < 0 || dt > 1 || (dt == 1 && np == 3); };
   if (bad(fwd_parts, fwd_dtype) || bad(bwd_parts, bwd_dtype))
     return fail(RLN_ERR_ARG, "parts in 0..3 (f16: 0..2), dtype 0 (bf16) or 1 (f16)");
@@ -2307,6 +2312,7 @@ int rln_set_dense_arith(rln_ctx* c, int fwd_parts, int fwd_dtype, int bwd_parts,
 }
 
 int rln_set_storage(rln_ctx* c, int mode) {
+  c->eval_tables_valid = 0;
   if (mode != 0 && mode != 1) return fail(RLN_ERR_ARG, "storage mode 0 (fp32 stacks) or 1 (bf16 stacks)");
   c->storage = mode;
   if (mode == 1) {  // bf16 stacks are read as plain bf16 MFMA operands everywhere (fp32 accumulation and statistics)
@@ -2327,6 +2333,7 @@ int rln_set_wgrad_parts(rln_ctx* c, int parts) {
 }
 
 int rln_bind_params(rln_ctx* c, float* params, float* grads, float* bn_running, int64_t* nbt) {
+  c->eval_tables_valid = 0;
   if (!params || !bn_running) return fail(RLN_ERR_ARG, "params and bn_running are required");
   c->params = params;
   c->grads = grads;
@@ -2341,6 +2348,7 @@ size_t rln_workspace_bytes(const rln_ctx* c, int n, int h, int w, int with_backw
 }
 
 int rln_set_workspace(rln_ctx* c, void* ws, size_t bytes, int n, int h, int w, int with_backward) {
+  c->eval_tables_valid = 0;
   if (n < 1 || h < 1 || w < 1) return fail(RLN_ERR_ARG, "bad geometry %dx%dx%d", n, h, w);
   if ((h >> c->cfg.n_down) < 1 || (w >> c->cfg.n_down) < 1)
     return fail(RLN_ERR_ARG, "input %dx%d too small for %d poolings (Output size is too small)", h, w, c->cfg.n_down);
@@ -2405,19 +2413,24 @@ int rln_forward(rln_ctx* c, const float* x, int n, int h, int w, int training, c
     if (c->nbt) RLN_TRY(add_one_i64((long long*)c->nbt, c->n_nbt, s));
   }
   c->prep_done = -1;
-  if (c->d3_units_f > 0)
+  // frozen-model loops (rln_set_eval_cache): the forward weight fragments and the folded BatchNorm tables of the
+  // previous eval forward are still those of the arena
+  c->eval_reuse = (!training && c->eval_cache_on && c->eval_tables_valid) ? 1 : 0;
+  const bool pack_fwd = !c->eval_reuse;
+  if (training) c->eval_tables_valid = 0;  // batch-statistics tables replace the eval ones
+  if (c->d3_units_f > 0 && pack_fwd)
     RLN_TRY(d3_pack_weights(c->params, c->d3_desc_f_dev, (int)c->d3_desc_f.size(), c->d3_units_f, c->d3_packed,
                             c->d3_fwd_np, c->d3_fwd_dt, s));
   if (c->d3_units_b > 0 && training && c->with_bwd)
     RLN_TRY(d3_pack_weights(c->params, c->d3_desc_b_dev, (int)c->d3_desc_b.size(), c->d3_units_b, c->d3_packed,
                             c->d3_bwd_np, c->d3_bwd_dt, s));
-  if (c->c3_units_f > 0)
+  if (c->c3_units_f > 0 && pack_fwd)
     RLN_TRY(c3_pack_weights(c->params, c->c3_desc_f_dev, (int)c->c3_desc_f.size(), c->c3_units_f, c->d3_packed,
                             c->d3_fwd_np, c->d3_fwd_dt, s));
   if (c->c3_units_b > 0 && training && c->with_bwd)
     RLN_TRY(c3_pack_weights(c->params, c->c3_desc_b_dev, (int)c->c3_desc_b.size(), c->c3_units_b, c->d3_packed,
                             c->d3_bwd_np, c->d3_bwd_dt, s));
-  if (c->p1_units_f > 0)
+  if (c->p1_units_f > 0 && pack_fwd)
     RLN_TRY(p1_pack_weights(c->params, c->p1_desc_f_dev, (int)c->p1_desc_f.size(), c->p1_units_f, c->d3_packed,
                             c->d3_fwd_np, c->d3_fwd_dt, s));
   if (c->p1_units_b > 0 && training && c->with_bwd)
@@ -2433,6 +2446,14 @@ int rln_forward(rln_ctx* c, const float* x, int n, int h, int w, int training, c
   c->last_x = x;
   c->have_train_fwd = training ? 1 : 0;
   c->have_loss = 0;
+  if (!training && c->eval_cache_on) c->eval_tables_valid = 1;
+  c->eval_reuse = 0;
+  return 0;
+}
+
+int rln_set_eval_cache(rln_ctx* c, int enable) {
+  c->eval_cache_on = enable ? 1 : 0;
+  c->eval_tables_valid = 0;
   return 0;
 }
 

@@ -43,5 +43,8 @@ def predict_frames(model, frames: torch.Tensor, transform=None, want_pred=False)
     """frames uint8 [N,Hs,Ws,3] BGR on the GPU -> painted uint8 [N,120,160,3] frames (makeDemoVideo.py:26-46)."""
     from .dataManagement.myTransforms import MyTransform
     transform = transform or MyTransform(augment=False)
+    if hasattr(model, "rln_eval_cache") and not model.training and not getattr(model, "_rln_demo_cached", False):
+        model.rln_eval_cache(True)  # the video loop runs a frozen model: weight fragments / BN tables are built once
+        object.__setattr__(model, "_rln_demo_cached", True)
     x, _ = transform(frames)
     return overlay(frames, model.forward(x), want_pred=want_pred)

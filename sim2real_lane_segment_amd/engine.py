@@ -112,6 +112,9 @@ class Engine:
             self.seg_ranges.append((b.value, e.value))
         self.device = torch.device("cpu")
         self.params = self.grads = self.bnrun = self.nbt = None
+        self._eval_cache = False
+        self._eval_key = None
+        self._param_epoch = 0  # bumped by the engine-side optimiser steps (they write the arena through raw pointers)
         self.views: Dict[str, torch.Tensor] = {}
         self._grad_views: Dict[str, torch.Tensor] = {}
         self._grad_views_of = None
@@ -215,6 +218,23 @@ class Engine:
         self._ws = None
         self._ws_key = None
 
+    def set_eval_cache(self, enable=True):
+        """Frozen-model loops (makeDemoVideo.py:15-47, test.py:80-94): eval forwards reuse the weight fragments and the
+        folded BatchNorm tables of the previous eval forward instead of rebuilding them on every call
+        (rln_set_eval_cache, include/rln.h).  The tables are rebuilt whenever torch's version counters of the parameter
+        / running-statistics arenas moved (optimiser steps, load_state_dict, any in-place write through the module's
+        parameters) or an engine-side optimiser step ran; writes that bypass the counters (`tensor.data`, raw
+        pointers) need another set_eval_cache(True) call.  Results are bit-identical to the uncached forward."""
+        self._eval_cache = bool(enable)
+        self._eval_key = None
+        _lib.check(self.L.rln_set_eval_cache(self.ctx, int(self._eval_cache)), "rln_set_eval_cache")
+
+    def _eval_cache_check(self):
+        key = (self.params._version, self.bnrun._version, self._param_epoch, self.params.data_ptr())
+        if key != self._eval_key:
+            _lib.check(self.L.rln_set_eval_cache(self.ctx, 1), "rln_set_eval_cache")  # invalidates
+            self._eval_key = key
+
     @property
     def wgrad_parts(self):
         return int(self.L.rln_get_wgrad_parts(self.ctx))
@@ -264,6 +284,8 @@ class Engine:
         if seed is None:
             self.step_seed += 1
             seed = self.step_seed
+        if self._eval_cache and not training:
+            self._eval_cache_check()
         _lib.check(self.L.rln_forward(self.ctx, _ptr(x), n, h, w, int(training), _ptr(drop_scales), int(seed),
                                       _ptr(probs), _ptr(feat), int(use_softmax), _stream()), "rln_forward")
         self._keep = [x, drop_scales]  # the backward pass re-reads the input
@@ -309,6 +331,7 @@ class Engine:
         """Nesterov SGD on the arena range [lo, hi) (one parameter group)."""
         self._require_gpu()
         gptr = ctypes.c_void_p((grads_ptr if grads_ptr is not None else self.grads.data_ptr()) + 4 * lo)
+        self._param_epoch += 1
         _lib.check(self.L.rln_sgd_step(_ptr(self.params[lo:hi]), gptr, _ptr(momentum_buf[lo:hi]), hi - lo, float(lr),
                                        float(momentum), float(weight_decay), int(first_step), float(grad_scale),
                                        _stream()), "rln_sgd_step")
@@ -331,6 +354,7 @@ class Engine:
                    grad_scale=1.0, lo=0, hi=None):
         self._require_gpu()
         hi = self.n_param if hi is None else hi
+        self._param_epoch += 1
         _lib.check(self.L.rln_adamw_step(_ptr(self.params[lo:hi]), _ptr(self.grads[lo:hi]), _ptr(exp_avg[lo:hi]),
                                          _ptr(exp_avg_sq[lo:hi]), hi - lo, lr, betas[0], betas[1], eps,
                                          weight_decay, int(step), grad_scale, _stream()), "rln_adamw_step")
@@ -340,6 +364,7 @@ def _adamw_step_ptr(self, grads_ptr, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 
                     grad_scale=1.0):
     """AdamW over the whole arena with gradients at an arbitrary flat device address."""
     self._require_gpu()
+    self._param_epoch += 1
     _lib.check(self.L.rln_adamw_step(_ptr(self.params), ctypes.c_void_p(grads_ptr), _ptr(exp_avg), _ptr(exp_avg_sq),
                                      self.n_param, lr, betas[0], betas[1], eps, weight_decay, int(step), grad_scale,
                                      _stream()), "rln_adamw_step")

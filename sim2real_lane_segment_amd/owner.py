@@ -32,6 +32,15 @@ class EngineOwner:
     _rln_dummy_classifier = None
     _rln_reducer = None
 
+    def rln_eval_cache(self, enable: bool = True):
+        """Frozen-model loops (makeDemoVideo.py:15-47, test.py:80-94: `model.eval()`, one forward per frame): eval
+        forwards reuse the MFMA weight fragments and the folded BatchNorm tables instead of rebuilding them per call
+        (Engine.set_eval_cache).  In-place writes through the module's parameters / buffers (optimisers,
+        load_state_dict) are noticed through torch's version counters; `tensor.data` writes are not -- call this
+        again after those.  Off by default."""
+        self._rln_sync().set_eval_cache(enable)
+        return self
+
     def enable_grad_allreduce(self, n_buckets: int = 4, group=None, force_collectives: bool = False):
         """Data-parallel training through the module path (what Lightning drives: training_step -> loss.backward() ->
         optimizer.step(), train.py:63-64): every backward of this module runs its segments bucket by bucket and

@@ -609,3 +609,52 @@ def test_stale_backward_and_standalone_pieces_fail_loudly():
         model.classifier(feat.requires_grad_(True))
     model.eval()
     assert model.classifier(feat.detach()).shape == (1, 4, 32, 48)
+
+
+def test_eval_cache_reuses_tables_bit_identically():
+    """rln_set_eval_cache (frozen-model loops, makeDemoVideo.py:15-47): eval forwards that reuse the weight fragments and
+    folded BatchNorm tables are bit-identical to forwards that rebuild them; in-place parameter writes (torch version
+    counters), engine-side optimiser steps and training forwards (new running statistics) all trigger a rebuild."""
+    z = load("g16_32x48")
+    cfg = cfg_from_arrays(z, O.NetConfig)
+    n, h, w, seed = int(z["n"]), int(z["h"]), int(z["w"]), int(z["seed"])
+    eng = make_engine(cfg, O.init_state(cfg, seed))
+    x, y = synth_batch(n, h, w, cfg.n_classes, seed + 1)
+    x = x.cuda()
+
+    def fwd():
+        out = eng.forward(x, training=False)[0].clone()
+        torch.cuda.synchronize()
+        return out
+
+    p0 = fwd()
+    eng.set_eval_cache(True)
+    p1, p2, p3 = fwd(), fwd(), fwd()
+    assert torch.equal(p0, p1) and torch.equal(p0, p2) and torch.equal(p0, p3)
+    # a write through a parameter view moves the arena's version counter
+    name = next(k for k in eng.views if k.endswith("conv.weight"))
+    with torch.no_grad():
+        eng.views[name].mul_(1.25)
+    p4 = fwd()
+    eng.set_eval_cache(False)
+    p5 = fwd()
+    assert torch.equal(p4, p5) and not torch.equal(p4, p0)
+    # a training forward replaces the tables (batch statistics) and moves the running statistics
+    eng.set_eval_cache(True)
+    fwd()
+    eng.forward(x, training=True)
+    p6 = fwd()
+    eng.set_eval_cache(False)
+    p7 = fwd()
+    assert torch.equal(p6, p7) and not torch.equal(p6, p4)
+    # an engine-side optimiser step (raw-pointer write) bumps the engine's own epoch
+    eng.set_eval_cache(True)
+    fwd()
+    eng.grads.fill_(1e-3)
+    m = torch.zeros_like(eng.params)
+    v = torch.zeros_like(eng.params)
+    eng.adamw_step(m, v, 1, 1e-2)
+    p8 = fwd()
+    eng.set_eval_cache(False)
+    p9 = fwd()
+    assert torch.equal(p8, p9) and not torch.equal(p8, p6)
