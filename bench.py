@@ -34,7 +34,8 @@ PMC_SUMMARY_BF16 = "r03_pmc_traffic_bf16.json"
 
 # kernel-name prefixes of each profiled class in the rocprofv3 --pmc summary
 CLASS_KERNELS = {
-    "dense3_fwd": ("void rln::d3_fwd_k<",),
+    "dense3_fwd": ("void rln::d3_fwd_k<10,",),
+    "dense3_fwd_small": ("void rln::d3_fwd_k<5,",),
     "dense3_wgrad": ("void rln::d3_wgrad_k<",),
     "dense3_dgrad_pull": ("void rln::d3_pull_k<",),
     "dense_conv3x3_fwd": ("void rln::igemm_k<3, 1, 1, 0,",),
@@ -42,7 +43,7 @@ CLASS_KERNELS = {
     "dense_conv3x3_wgrad": ("void rln::wgrad_dense_q_k<", "void rln::wgrad_k<3, 1, 1,"),
 }
 # classes that run on the 16-bit MFMA pipe with split operands: products issued per algorithmic multiply-add
-SPLIT_CLASSES = ("dense3_fwd", "dense3_wgrad", "dense3_dgrad_pull")
+SPLIT_CLASSES = ("dense3_fwd", "dense3_fwd_small", "dense3_wgrad", "dense3_dgrad_pull")
 
 
 def pmc_traffic(class_name, summary=None):
@@ -148,7 +149,7 @@ def roofline_of(prof, eng, instrumented_ms, images, elapsed, args):
     total_ms = sum(p["ms"] for p in timed)
     dom = max((p for p in timed if p["flops"] > 0), key=lambda p: p["ms"])
     fwd_parts, _, bwd_parts, _ = eng.dense_arith
-    parts = fwd_parts if dom["name"] == "dense3_fwd" else bwd_parts
+    parts = fwd_parts if dom["name"] in ("dense3_fwd", "dense3_fwd_small") else bwd_parts
     products = {1: 1, 2: 3, 3: 6}.get(parts, 1) if dom["name"] in SPLIT_CLASSES else 1
     if dom["name"] == "dense3_wgrad":
         products = {1: 1, 2: 3, 3: 6}.get(eng.wgrad_parts, 1)  # rln_set_wgrad_parts
@@ -166,7 +167,9 @@ def roofline_of(prof, eng, instrumented_ms, images, elapsed, args):
                 "frac": round(hbm_frac, 4)}
     summary = PMC_SUMMARY_BF16 if eng.storage == "bf16" else PMC_SUMMARY
     roof.update({
-        "kernel": dom["name"], "traffic": pmc_traffic(dom["name"], summary),
+        "kernel": dom["name"],
+        "kernel_symbol": " | ".join(CLASS_KERNELS.get(dom["name"], ("?",))) + "...>  (row of profiles/r03_kernel_stats_*.csv)",
+        "traffic": pmc_traffic(dom["name"], summary),
         "traffic_unit": f"HBM bytes per launch (rocprofv3 --pmc pass, profiles/{summary})",
         "alg_bytes_per_launch": round(dom["bytes"] / dom["launches"]), "launches": dom["launches"],
         "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),

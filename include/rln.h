@@ -255,6 +255,9 @@ int rln_profile_enable(rln_ctx* ctx, int on);
 int rln_profile_num_classes(void);
 const char* rln_profile_class_name(int cls);
 int rln_profile_read(rln_ctx* ctx, double* ms, double* flops, double* bytes, int64_t* launches);
+/* the same collection launch by launch (in issue order): class id, device time, algorithmic flops / bytes of up to `cap`
+ * entries; returns the number of entries recorded (may exceed cap), < 0 on error */
+int64_t rln_profile_entries(rln_ctx* ctx, int* cls, double* ms, double* flops, double* bytes, int64_t cap);
 
 /* diagnostic only: in-kernel cycle stamps of the dense forward kernel (enabled by env RLN_DBG=16) */
 int rln_debug_read_stamps(unsigned long long* out8);

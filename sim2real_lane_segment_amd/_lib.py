@@ -90,6 +90,8 @@ _PROTOS = {
     "rln_profile_enable": (c_int, [c_void_p, c_int]),
     "rln_profile_num_classes": (c_int, []),
     "rln_profile_class_name": (c_char_p, [c_int]),
+    "rln_profile_entries": (ctypes.c_int64, [c_void_p, POINTER(c_int), POINTER(ctypes.c_double), POINTER(ctypes.c_double),
+                            POINTER(ctypes.c_double), c_int64]),
     "rln_profile_read": (c_int, [c_void_p, POINTER(ctypes.c_double), POINTER(ctypes.c_double),
                                  POINTER(ctypes.c_double), POINTER(c_int64)]),
     "rln_debug_read_stamps": (c_int, [POINTER(ctypes.c_uint64)]),

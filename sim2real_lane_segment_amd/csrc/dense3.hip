@@ -1232,7 +1232,12 @@ int d3_pull_finalize(const D3PullFin& f, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
-int d3_pull_nsub(const D3Pull& p) { return p.C <= 16 ? 5 : 2; }  // work items per (group, tile): see d3_pull_k
+// work items per (group, tile): see d3_pull_k.  (Measured and not kept: whole-tile items, MT = 10, for ranges of >= 8
+// groups -- half the weight-fragment fetches per pixel, but 256 VGPRs + 476 B of spills per lane: the level-0 up-block
+// launch 1.62 -> 2.93 ms.  An ablation that never re-fetches the fragments changes nothing (1.64 -> 1.61 ms): the 10 KB
+// per (item, layer) from L2 are not what the item loop waits for; the exposed parts are the tile's dY staging between
+// two barriers (105 KB per tile with one block per CU) and 26 items over 8 waves.)
+int d3_pull_nsub(const D3Pull& p) { return p.C <= 16 ? 5 : 2; }
 
 static size_t d3_pull_lds(const D3Pull& p, int np) {
   const int P = p.tw + 3, rows = p.th + 2;

@@ -98,13 +98,13 @@ struct Level {
 enum ProfClass {
   PC_DENSE_FWD = 0, PC_FIRST_FWD, PC_TD_FWD, PC_TU_FWD, PC_DENSE_DGRAD, PC_TD_DGRAD, PC_TU_DGRAD, PC_DENSE_WGRAD,
   PC_FIRST_WGRAD, PC_TD_WGRAD, PC_TU_WGRAD, PC_BN, PC_GRADFIN, PC_REDUCE, PC_HEAD_FWD, PC_LOSS, PC_HEAD_BWD,
-  PC_D3_FWD, PC_D3_PULL, PC_D3_WGRAD, PC_COUNT
+  PC_D3_FWD, PC_D3_PULL, PC_D3_WGRAD, PC_D3_FWD_S, PC_COUNT
 };
 static const char* kProfNames[PC_COUNT] = {
     "dense_conv3x3_fwd", "first_conv_fwd", "transition_down_fwd", "transition_up_fwd", "dense_conv3x3_dgrad",
     "transition_down_dgrad", "transition_up_dgrad", "dense_conv3x3_wgrad", "first_conv_wgrad",
     "transition_down_wgrad", "transition_up_wgrad", "bn_stats_affine", "grad_finalize", "partial_reduce",
-    "head_fwd", "loss", "head_bwd", "dense3_fwd", "dense3_dgrad_pull", "dense3_wgrad"};
+    "head_fwd", "loss", "head_bwd", "dense3_fwd", "dense3_dgrad_pull", "dense3_wgrad", "dense3_fwd_small"};
 struct ProfEntry {
   hipEvent_t a, b;
   int cls;
@@ -1035,7 +1035,9 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
       {
         const double flops = 2.0 * o.cin * o.cout * 9.0 * q.H * q.W * N;
         const double bytes = (double)st_bytes(dl.st) * N * ((double)o.cin + o.cout) * q.H * q.W;
-        ProfScope ps(c, PC_D3_FWD, flops, bytes, s);
+        // one class per kernel instantiation, so that a class's average launch time is a row of the rocprofv3 summary:
+        // d3_fwd_k<10, ...> (tiles of up to 640 pixels: the wide levels) / d3_fwd_k<5, ...> (<= 320 pixels)
+        ProfScope ps(c, q.th * q.tw > 320 ? PC_D3_FWD : PC_D3_FWD_S, flops, bytes, s);
         e3 = d3_fwd_launch(q, N, c->d3_fwd_np, c->d3_fwd_dt, s);
       }
       // RLN_ERR_UNSUPPORTED from the launcher (tile / LDS budget of an unusual geometry) falls through to the exact-fp32
@@ -1044,7 +1046,7 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
         return fail(e3, "d3_fwd_launch failed with %d (op %zu)", e3, k);
       if (e3 == 0 && sp3 > 1) {
         long long nblk = 0;
-        ProfScope ps(c, PC_D3_FWD, 0, 0, s);
+        ProfScope ps(c, PC_REDUCE, 0, 0, s);
         RLN_TRY(splitk_finish(c->fsplit, sp3, q.split_stride, N, o.cout, dl.H * dl.W, p.bias, p.nscale, p.out, p.out_ns,
                               p.stat_partial, &nblk, s));
         if (training) RLN_TRY(finalize_stats(c, o.dst_level, o.out_off, o.cout, nblk, s, (long long)k));
@@ -3122,6 +3124,23 @@ int rln_profile_read(rln_ctx* c, double* ms, double* flops, double* bytes, int64
     launches[e.cls] += 1;
   }
   return 0;
+}
+
+int64_t rln_profile_entries(rln_ctx* c, int* cls, double* ms, double* flops, double* bytes, int64_t cap) {
+  int64_t i = 0;
+  for (ProfEntry& e : c->prof.entries) {
+    if (i < cap) {
+      if (hipEventSynchronize(e.b) != hipSuccess) return -1;
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, e.a, e.b) != hipSuccess) return -1;
+      cls[i] = e.cls;
+      ms[i] = t;
+      flops[i] = e.flops;
+      bytes[i] = e.bytes;
+    }
+    ++i;
+  }
+  return i;
 }
 
 // ---- EncDecNet building blocks (models/EncDecNet.py) ------------------------------------------------------
