@@ -117,6 +117,7 @@ struct D3Pull {
   int th, tw, tiles_x, tiles_y;
   float* stat_partial;            // [nsub*blocks][nl][Cpad][2], Cpad = 16*ceil(C/16), nsub = d3_pull_nsub()
   int st;                         // storage element type of S and of the dY buffers (storage.h); G is fp32
+  unsigned long long* dbg_out;    // diagnostic builds (-DRLN_DIAG): 8 phase cycle sums (see d3_pull_k), or null
 };
 bool d3_pull_supported(const D3Pull& p, int np);  // geometry + LDS budget (set nl, C, th, tw first)
 void d3_pull_pick_tile(int H, int W, int* th, int* tw);

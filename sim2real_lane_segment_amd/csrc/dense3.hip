@@ -1,5 +1,6 @@
 // Dense-block 3x3 kernels on the 16-bit MFMA pipe with split fp32 operands (see dense3.h).
 #include "dense3.h"
+#include "igemm.h"
 #include "split16.h"
 #include "storage.h"
 
@@ -976,11 +977,29 @@ __global__ __launch_bounds__(512, 2) void d3_pull_k(const D3Pull p) {
     toff[s] = ((tap / 3 - 1) * P + (tap % 3 - 1)) * 32;
   }
 
+#ifdef RLN_DIAG
+  // phase stamps (wave cycles summed over all waves; tools/pull_stamps.py): 0 wait at the tile barrier, 1 dY staging,
+  // 2 wait for the staged tile, 3 item / layer set-up, 4 MFMA loops, 5 layer epilogues, 6 G read-modify-write, 7 items
+  unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+#define D3P_STAMP(k)                                             \
+  do {                                                           \
+    __builtin_amdgcn_sched_barrier(0);                           \
+    const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                          \
+    tph[k] += tn_ - tlast;                                       \
+    tlast = tn_;                                                 \
+    __builtin_amdgcn_sched_barrier(0);                           \
+  } while (0)
+#else
+#define D3P_STAMP(k) do {} while (0)
+#endif
   for (int t = blockIdx.x; t < total; t += gridDim.x) {
     const int n = t / tiles, tl = t - n * tiles;
     const int tile_y = tl / p.tiles_x, tile_x = tl - tile_y * p.tiles_x;
     const int gy0 = tile_y * p.th, gx0 = tile_x * p.tw;
     __syncthreads();  // previous tile's images are no longer read (also orders the stats zeroing)
+    D3P_STAMP(0);
     // ---- stage the dY images (zero outside the picture and beyond Cout): all loads first, then convert ----
     {
       constexpr int NRD = 2;  // staging rounds (nl * lul <= 1024: checked by the launcher)
@@ -1057,7 +1076,9 @@ __global__ __launch_bounds__(512, 2) void d3_pull_k(const D3Pull p) {
         for (int pt = 0; pt < NP; ++pt) *reinterpret_cast<unsigned*>(smem + hdst + pt * PLANE) = parts[pt];
       }
     }
+    D3P_STAMP(1);
     __syncthreads();
+    D3P_STAMP(2);
 
     // ---- per-wave loop over work items (no barriers) ----
     const SP<ST> Sn = SP<ST>(p.S) + (long long)n * p.s_ns;
@@ -1129,6 +1150,7 @@ __global__ __launch_bounds__(512, 2) void d3_pull_k(const D3Pull p) {
         }
         constexpr int DEPTH = 4, RING = DEPTH + 1, STEPS = 5 * MT;
         uint4 af[RING][NP];
+        D3P_STAMP(3);
 #pragma unroll
         for (int i = 0; i < DEPTH; ++i) {
           const int s0 = i / MT, m0 = i - s0 * MT;
@@ -1154,6 +1176,10 @@ __global__ __launch_bounds__(512, 2) void d3_pull_k(const D3Pull p) {
           __builtin_amdgcn_sched_barrier(0);
         }
         // epilogue of layer j: ReLU mask of the layer's BatchNorm output, BN-backward sums, gamma-weighted sum
+#ifdef RLN_DIAG
+        asm volatile("" ::"v"(acc[0][0]), "v"(acc[MT - 1][3]));
+#endif
+        D3P_STAMP(4);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -1176,6 +1202,7 @@ __global__ __launch_bounds__(512, 2) void d3_pull_k(const D3Pull p) {
           st[0] += s1;
           st[1] += s2;
         }
+        D3P_STAMP(5);
       }
       // write G once (the activations are dead by now: their registers take the old gradient where it accumulates)
 #pragma unroll
@@ -1187,8 +1214,18 @@ __global__ __launch_bounds__(512, 2) void d3_pull_k(const D3Pull p) {
           *reinterpret_cast<float4*>(Gc + goff[m]) = make_float4(gsum[m][0] + sv[m].x, gsum[m][1] + sv[m].y,
                                                                  gsum[m][2] + sv[m].z, gsum[m][3] + sv[m].w);
       }
+      D3P_STAMP(6);
+#ifdef RLN_DIAG
+      tph[7] += 1;
+#endif
     }
   }
+#ifdef RLN_DIAG
+  if (lane == 0 && p.dbg_out != nullptr) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) atomicAdd(&p.dbg_out[k], tph[k]);
+  }
+#endif
   __syncthreads();
   if (p.stat_partial != nullptr) {  // rows: [block][sub]
     float* dst = p.stat_partial + (long long)blockIdx.x * NSUB * p.nl * Cpad * 2;
@@ -1235,8 +1272,13 @@ int d3_pull_finalize(const D3PullFin& f, hipStream_t s) {
 // work items per (group, tile): see d3_pull_k.  (Measured and not kept: whole-tile items, MT = 10, for ranges of >= 8
 // groups -- half the weight-fragment fetches per pixel, but 256 VGPRs + 476 B of spills per lane: the level-0 up-block
 // launch 1.62 -> 2.93 ms.  An ablation that never re-fetches the fragments changes nothing (1.64 -> 1.61 ms): the 10 KB
-// per (item, layer) from L2 are not what the item loop waits for; the exposed parts are the tile's dY staging between
-// two barriers (105 KB per tile with one block per CU) and 26 items over 8 waves.)
+// per (item, layer) from L2 are not what the item loop waits for.  In-kernel stamps of the level-0 up-block launch
+// (tools/pull_stamps.py, wave cycles): MFMA loops 29 %, layer epilogues 22 %, item / layer set-up 15 %, G tail 15 %
+// (26 % with bf16 stacks), dY staging + its two barriers 20 %.  The G tail guards its loads and stores per lane and the
+// compiler keeps an s_cbranch_execz around each, so the wait-count pass drains every outstanding memory operation
+// there; straight-line tails for whole-tile / all-or-nothing-accumulate launches (two more template variants) plus the
+// first fragment load hoisted out of the item loop brought the stamped tail to 11 % but the step from 24.48 to 24.62 ms
+// (A/B on one box, tools/ab_bench.sh): not kept.)
 int d3_pull_nsub(const D3Pull& p) { return p.C <= 16 ? 5 : 2; }
 
 static size_t d3_pull_lds(const D3Pull& p, int np) {
@@ -1295,6 +1337,14 @@ static int d3_pull_launch_m(const D3Pull& p, hipStream_t s) {
       return (int)attr_err;
     }
   }
+#ifdef RLN_DIAG
+  if (rln_env("RLN_PULL_STAMPS") && p.C >= atoi(rln_env("RLN_PULL_STAMPS"))) {  // stamps of the launches with >= that many channels
+    D3Pull q = p;
+    q.dbg_out = igemm_debug_buffer();
+    hipLaunchKernelGGL(kern, dim3((unsigned)d3_pull_blocks(p)), dim3(512), lds, s, q);
+    return (int)hipGetLastError();
+  }
+#endif
   hipLaunchKernelGGL(kern, dim3((unsigned)d3_pull_blocks(p)), dim3(512), lds, s, p);
   return (int)hipGetLastError();
 }
