@@ -84,6 +84,8 @@ struct D3Wgrad {
   float* partial;  // [nranges][Cout*Cin*9], layout [o][c][tap]
   int dbg;         // diagnostic builds (-DRLN_DIAG) only: 1 no global loads, 2 no commit, 4 no MFMA phase
   int st;          // storage element type of S and dY (storage.h)
+  const void* dY16;  // fp32 stacks only: bf16 copy of dY written by grad_finalize (GradFinParams.dst16), or null
+  int yt;            // ST_BF16 with st == ST_F32: read dY16 instead of dY (one bf16 part); otherwise ignored
 };
 bool d3_wgrad_supported(const D3Wgrad& p);
 void d3_wgrad_plan(int H, int W, int N, int Cin, D3Wgrad* p);  // fills th, tw, tiles, rg, nchunks, nranges

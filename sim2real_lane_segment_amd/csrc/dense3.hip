@@ -529,8 +529,14 @@ __device__ __forceinline__ uint2 lds_tr16(const unsigned char* p) {
 // (Measured with bf16 stacks and not kept: <= 80 VGPRs + one staging register set + 512 blocks = two workgroups per CU:
 // 4.4 -> 5.1 ms per step.  The second register set -- a tile's loads in flight for two iterations -- is worth more than a
 // partner workgroup.)
-template <int NP, int DT, int ST>
+// YT: storage type of the dY the kernel reads.  (ST, YT) = (fp32, bf16) is the default mode's weight gradient: its
+// one-part bf16 operand is rounded once by grad_finalize_k into a 2-byte copy (p.dY16) instead of by every one of the
+// Cin / 16 chunk blocks that re-read the tile -- the dY share of the staged bytes halves; a dY unit is then 8 channels
+// x 8 pixels (one 16-byte load per channel, like every other unit).
+template <int NP, int DT, int ST, int YT>
 __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
+  constexpr bool Y16 = (ST == ST_F32 && YT == ST_BF16);
+  static_assert(ST == YT || (Y16 && NP == 1 && DT == D3_BF16), "mixed storage: fp32 stacks with a bf16 dY copy, one bf16 part");
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool producer = wave >= 4;
@@ -598,10 +604,11 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
       const int yu = ptid - 256;
       u_o = yu & 1;
       const int y2 = yu >> 1;
-      u_r = y2 / nq;
-      u_q = y2 - u_r * nq;
+      const int nqy = Y16 ? (p.tw >> 3) : nq;  // units per row: 8 pixels each with the bf16 copy
+      u_r = y2 / nqy;
+      u_q = y2 - u_r * nqy;
       u_ex = u_r < p.th;
-      u_lds = ((u_ex ? u_r : 0) * p.tw + 4 * u_q) * 32 + u_o * 16;
+      u_lds = ((u_ex ? u_r : 0) * p.tw + (Y16 ? 8 : 4) * u_q) * 32 + u_o * 16;
     } else {
       const int hu = ptid - 416;
       u_o = hu & 3;  // channel quad
@@ -619,9 +626,11 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
       const int ch = kind == 0 ? cb + u_o * 8 + cc : (kind == 1 ? min(u_o * 8 + cc, p.Cout - 1) : cb + 4 * u_o + (cc & 3));
       choff[cc] = ch * p.cs;
     }
-    typedef typename SRaw<ST>::r4 Raw4;  // S and dY share the level's storage type
+    typedef typename SRaw<ST>::r4 Raw4;  // every unit loads 8 x Raw4 (with Y16 a dY unit's 16 bytes hold 8 bf16 pixels)
     const SP<ST> kbase(kind == 1 ? p.dY : p.S);
     const long long kns = kind == 1 ? (long long)p.Cout * p.cs : p.ns;
+    const unsigned char* kbytes = reinterpret_cast<const unsigned char*>(kind == 1 ? p.dY16 : (const void*)p.S);
+    const int kes = (Y16 && kind == 1) ? 2 : 4;  // bytes per element of this thread's operand
     Raw4 regA[8], regB[8];
     bool okA = false, okB = false;
     // tiles are requested strictly in order t0, t0+1, ...: a cursor replaces two integer divisions per request
@@ -644,7 +653,7 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
         ok = u_ex && iy >= 0 && iy < p.H && ix < p.W;
       } else if (kind == 1) {
         iy = gy0 + u_r;
-        ix = gx0 + 4 * u_q;
+        ix = gx0 + (Y16 ? 8 : 4) * u_q;
         ok = u_ex && iy < p.H && ix < p.W;
       } else {  // halo pixel: the aligned quad that holds it (left: last element of the quad, right: first)
         iy = gy0 - 1 + u_r;
@@ -652,12 +661,18 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
         ok = u_ex && iy >= 0 && iy < p.H && hx >= 0 && hx < p.W;
         ix = h_side ? hx : hx - 3;
       }
-      const SP<ST> src = kbase + ((long long)n * kns + (ok ? iy * p.W + ix : 0));
+      if constexpr (Y16) {  // one byte-addressed form for both element sizes: the same 8 dwordx4 loads in every thread
+        const unsigned char* srcb = kbytes + ((long long)n * kns + (ok ? iy * p.W + ix : 0)) * kes;
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) reg[cc] = *reinterpret_cast<const Raw4*>(srcb + (long long)choff[cc] * kes);
+      } else {
+        const SP<ST> src = kbase + ((long long)n * kns + (ok ? iy * p.W + ix : 0));
 #ifdef RLN_DIAG
-      if (!(p.dbg & 1) && !((p.dbg & 8) && kind == 1) && !((p.dbg & 16) && kind != 1))
+        if (!(p.dbg & 1) && !((p.dbg & 8) && kind == 1) && !((p.dbg & 16) && kind != 1))
 #endif
 #pragma unroll
-      for (int cc = 0; cc < 8; ++cc) reg[cc] = src.raw4(choff[cc]);
+        for (int cc = 0; cc < 8; ++cc) reg[cc] = src.raw4(choff[cc]);
+      }
       okf = ok;
     };
     auto commit = [&](int buf, const Raw4 (&rawreg)[8], bool okf) __attribute__((always_inline)) {
@@ -683,6 +698,30 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
 #pragma unroll
         for (int pt = 0; pt < NP; ++pt) *reinterpret_cast<uint2*>(zb + pt * PLZ + u_lds) = make_uint2(pa[pt], pb2[pt]);
         return;
+      }
+      if constexpr (Y16) {
+        if (kind == 1) {  // 8 channels x 8 bf16 pixels, already rounded: interleave the channels per pixel
+          unsigned wv[8][4];
+#pragma unroll
+          for (int cc = 0; cc < 8; ++cc) {
+            const bool cv = okf && (u_o * 8 + cc < p.Cout);
+            wv[cc][0] = cv ? __builtin_bit_cast(unsigned, rawreg[cc].x) : 0u;
+            wv[cc][1] = cv ? __builtin_bit_cast(unsigned, rawreg[cc].y) : 0u;
+            wv[cc][2] = cv ? __builtin_bit_cast(unsigned, rawreg[cc].z) : 0u;
+            wv[cc][3] = cv ? __builtin_bit_cast(unsigned, rawreg[cc].w) : 0u;
+          }
+#pragma unroll
+          for (int px = 0; px < 8; ++px) {
+            unsigned o4[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const unsigned a = wv[2 * k][px >> 1], b = wv[2 * k + 1][px >> 1];
+              o4[k] = (px & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+            }
+            *reinterpret_cast<uint4*>(yb + u_lds + px * 32) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+          }
+          return;
+        }
       }
       // kind 0: z = relu(a*x + b) of 8 channels x 4 pixels; kind 1: dY as it is (zero beyond Cout); zero outside
       float av[8], bv[8];
@@ -868,12 +907,12 @@ void d3_wgrad_plan(int H, int W, int N, int Cin, D3Wgrad* p) {
   p->nranges = (int)((total + per - 1) / per);  // no empty ranges
 }
 
-template <int NP, int DT, int ST = ST_F32>
+template <int NP, int DT, int ST = ST_F32, int YT = ST>
 static int d3_wgrad_launch_t(const D3Wgrad& p, hipStream_t s) {
   const int P = p.tw + 3, rows = p.th + 2;
   const size_t lds = (size_t)2 * NP * rows * P * 32 + (size_t)2 * NP * p.th * p.tw * 32 + 128;
   if (lds > 160 * 1024 || lds < 4 * 9 * 64 * 16) return -4;
-  auto kern = d3_wgrad_k<NP, DT, ST>;
+  auto kern = d3_wgrad_k<NP, DT, ST, YT>;
   static DevOnce attr_once;
   if (attr_once.first()) {
     const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -900,6 +939,12 @@ int d3_wgrad_launch(const D3Wgrad& p, int np, int dt, hipStream_t s) {
   if (p.st == ST_BF16) {
     if (np != 1 || dt != D3_BF16) return -4;
     return d3_wgrad_launch_t<1, D3_BF16, ST_BF16>(p, s);
+  }
+  if (p.yt == ST_BF16) {  // fp32 stacks + the bf16 copy of dY (one bf16 part; 8-pixel dY units)
+    if (np != 1 || dt != D3_BF16 || p.dY16 == nullptr || (p.tw & 7) || (reinterpret_cast<uintptr_t>(p.dY16) & 15) ||
+        (((long long)p.cs * 2) & 15) || p.th * (p.tw >> 3) * 2 > 160)
+      return -4;
+    return d3_wgrad_launch_t<1, D3_BF16, ST_F32, ST_BF16>(p, s);
   }
   if (dt == D3_BF16) {
     if (np == 1) return d3_wgrad_launch_t<1, D3_BF16>(p, s);

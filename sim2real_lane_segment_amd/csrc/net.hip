@@ -164,6 +164,7 @@ struct rln_ctx {
   hipEvent_t ev_wg[2] = {nullptr, nullptr};  // last weight-gradient reading dY[buf] finished (side stream)
   bool wg_pending[2] = {false, false};
   float* dYbuf[2] = {nullptr, nullptr};
+  void* dy16 = nullptr;  // bf16 copy of a dense layer's finalised output gradient (the weight gradient's one-part operand)
   int dy_flip = 0;
   bool use_side = false;
   // forward/backward hand-over state
@@ -651,6 +652,7 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
   float* fsplit = cv.take<float>(fs_max);
   float* dY = with_bwd ? cv.take<float>(dy_max) : nullptr;
   float* dY2 = with_bwd ? cv.take<float>(dy_max) : nullptr;
+  float* dy16 = with_bwd ? cv.take<float>((dy_max + 1) / 2) : nullptr;  // dy_max bf16 elements
   float* wpartial = with_bwd ? cv.take<float>(wp_max) : nullptr;
   float* bpartial = with_bwd ? cv.take<float>(bp_max) : nullptr;
   float* glin = with_bwd ? cv.take<float>((size_t)n * c->cfg.n_classes * hw0) : nullptr;
@@ -798,6 +800,7 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
     c->dY = dY;
     c->dYbuf[0] = dY;
     c->dYbuf[1] = dY2;
+    c->dy16 = dy16;
     c->wpartial = wpartial;
     c->bpartial = bpartial;
     c->glin = glin;
@@ -1229,7 +1232,7 @@ HeadParams head_params(rln_ctx* c) {
 // ---------------------------------------------------------------------------------------------
 
 int finalize_grad_range(rln_ctx* c, int level, int ch_off, int C, const float* nscale, long long* rows,
-                        hipStream_t s, float* dst = nullptr, int yt = -1) {
+                        hipStream_t s, float* dst = nullptr, int yt = -1, void* dst16 = nullptr) {
   const Level& lv = c->levels[level];
   GradFinParams g;
   memset(&g, 0, sizeof(g));
@@ -1253,7 +1256,8 @@ int finalize_grad_range(rln_ctx* c, int level, int ch_off, int C, const float* n
   g.Wd = lv.W;
   g.st = lv.st;
   g.yt = yt < 0 ? lv.st : yt;  // the finalised gradients share the level's storage type unless the consumer asks otherwise
-  ProfScope ps(c, PC_GRADFIN, 0, (4.0 + st_bytes(lv.st) + st_bytes(g.yt)) * c->N * C * plane, s);
+  g.dst16 = dst16;
+  ProfScope ps(c, PC_GRADFIN, 0, (4.0 + st_bytes(lv.st) + st_bytes(g.yt) + (dst16 ? 2.0 : 0.0)) * c->N * C * plane, s);
   RLN_TRY(grad_finalize(g, c->N, rows, s));
   return 0;
 }
@@ -2030,7 +2034,13 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
       const int alo = std::min(std::max(last_op.acc_lo - lo, 0), gr), ahi = std::min(std::max(last_op.acc_hi - lo, 0), gr);
       RLN_TRY(pull_range(lo, gr, j + 1, L - 1, alo, ahi, nullptr));
     }
-    RLN_TRY(finalize_grad_range(c, o.dst_level, o.out_off, o.cout, nscale, &rows, s, dYj));
+    // the dense weight gradient's one-part bf16 operand is rounded here, once, into a 2-byte copy (dense3.h: dY16)
+    static const bool no_dy16 = rln_env("RLN_NO_DY16") != nullptr;
+    const bool use_dy16 = !no_dy16 && lv.st == ST_F32 && c->d3_bwd_np > 0 && c->d3_bwd_dt == D3_BF16 && o.cout <= 16 &&
+                          wgrad_parts(c, (long long)N * lv.H * lv.W) == 1 && (lv.W % 40) == 0 && c->dy16 != nullptr &&
+                          ((lv.H * lv.W) % 8) == 0;
+    RLN_TRY(finalize_grad_range(c, o.dst_level, o.out_off, o.cout, nscale, &rows, s, dYj, -1,
+                                use_dy16 ? c->dy16 : nullptr));
     // the layer's three small reductions (bias rows, weight slabs, BatchNorm-backward sums of its new-channel data
     // gradient) run as ONE launch at the end of the iteration when the weight gradient went through d3_wgrad_k
     DenseTail tail;
@@ -2075,6 +2085,10 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
         return fail(RLN_ERR_UNSUPPORTED, "dense weight gradient not covered by the bf16-storage kernel");
       if (d3_wgrad_supported(g)) {  // transposed-read 16-bit MFMA kernel
         d3_wgrad_plan(lv.H, lv.W, N, o.cin, &g);
+        if (use_dy16 && (g.tw % 8) == 0) {
+          g.dY16 = c->dy16;
+          g.yt = ST_BF16;
+        }
 #ifdef RLN_DIAG
         if (rln_env("RLN_D3_DBG")) g.dbg = atoi(rln_env("RLN_D3_DBG"));
 #endif

@@ -215,6 +215,7 @@ __global__ __launch_bounds__(256) void grad_finalize_k(const GradFinParams p) {
         const float xh = (Sp.ld1(e) - mean) * is;
         const float v = st_round<YT>(sc * is * (Gp[e] - k1 - xh * k2));  // the bias gradient sums what is stored
         dp.st1(e, v);
+        if (p.dst16 != nullptr) (SP<ST_BF16>(p.dst16) + ((long long)n * p.C + c) * dplane).st1(e, v);
         bsum += v;
       }
     }
