@@ -139,4 +139,36 @@ struct D3PullFin {
 };
 int d3_pull_finalize(const D3PullFin& f, hipStream_t s);
 
+// ---- data gradient of a dense layer into the block's OWN new channels ("looped" form on the 16-bit pipe) -------------
+// Layer j of a block also consumes the 16 * j channels the earlier layers of the same block produced; they can only be
+// finalised after layer j has contributed (BatchNorm-backward sums are grid-wide), so this contribution is a per-layer
+// read-modify-write of G.  Same contraction as the exact-fp32 dgrad_loop_k (igemm.h) -- K = the layer's 16 dY channels
+// x 9 flipped taps -- with the dY tile staged ONCE as a split 16-bit [pixel][16 channels] image and the backward-
+// orientation weight fragments of d3_pack_k (5 K-steps of 16 channels x 2 taps per 16-channel output group).
+struct D3Dgl {
+  const float* dY;   // [N][K][H][W], the layer's finalised output gradient (storage type st)
+  int K;             // its channels (<= 16)
+  const uint4* wpk;  // backward-orientation fragments of the layer, at the first output group
+  int J;             // output (new) channels
+  const float* S;    // stack view at the first output channel (storage type st)
+  long long s_ns;    // sample stride of S and G (elements)
+  int cs;            // plane stride
+  float* G;          // gradient stack view (fp32), same geometry
+  const float* ea;   // BN folded scale / shift of the layer (ReLU mask), at the first output channel
+  const float* eb;
+  const float* emean;
+  const float* einvstd;
+  const float* egamma;
+  int acc_lo, acc_hi;  // output channels in [acc_lo, acc_hi) accumulate into G, the others overwrite
+  int H, W, N;
+  int tile;            // 0: 8 x 32, 1: 16 x 16 pixel tiles
+  int tiles_x, tiles_y;
+  float* stat_partial;  // [N * tiles][J][2]
+  int st;
+};
+bool d3_dgl_supported(const D3Dgl& p);
+void d3_dgl_plan(int H, int W, D3Dgl* p);  // tile, tiles_x, tiles_y
+inline long long d3_dgl_rows(const D3Dgl& p) { return (long long)p.tiles_x * p.tiles_y * p.N; }
+int d3_dgl_launch(const D3Dgl& p, int np, int dt, hipStream_t s);
+
 }  // namespace rln

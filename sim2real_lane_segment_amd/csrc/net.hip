@@ -2023,6 +2023,11 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
   // the work items does not hide it (vmcnt retires in order: the items' own S loads wait for the older prefetch too;
   // 25.6 ms).  Kept for diagnostic builds (RLN_LAYER_PULL).
   const bool layer_pull = gr == 16 && (C0 % 16) == 0 && rln_env("RLN_LAYER_PULL") != nullptr;
+  // The per-layer data gradient of the block's own new channels on the 16-bit pipe (d3_dgl_k) instead of the exact-fp32
+  // dgrad_loop_k, which is matrix-pipe bound at 1/16 of the 16-bit rate (profiles/r03_pmc_sq_f32.json: 50 % MFMA busy).
+  const bool dgl16 = c->d3_bwd_np > 0 && c->d3_bwd_dt == D3_BF16 && first.cout <= 16 && (C0 % 16) == 0 &&
+                     rln_env("RLN_NO_DGL") == nullptr;
+  D3Dgl dg;
 
   for (int j = L - 1; j >= 0; --j) {
     const Op& o = c->ops[(size_t)k0 + j];
@@ -2125,6 +2130,54 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
       tail.dbeta = c->grads + o.bn.beta + C0;
       tail.S1 = c->S1 + so;
       tail.S2 = c->S2 + so;
+    } else if (Jn > 0 && dgl16 && [&]() -> bool {  // the 16-bit looped form covers this geometry?
+                 memset(&dg, 0, sizeof(dg));
+                 dg.dY = dYj;
+                 dg.K = o.cout;
+                 dg.wpk = c->d3_packed + c->d3_wb_off[(size_t)k0 + j] + (long long)(C0 / 16) * 5 * c->d3_bwd_np * 64;
+                 dg.J = Jn;
+                 dg.S = lv.sp(o.in_off + C0);
+                 dg.s_ns = (long long)lv.C * plane;
+                 dg.cs = (int)plane;
+                 dg.G = lv.G + (size_t)(o.in_off + C0) * plane;
+                 dg.ea = c->ab + o.bn.ab + C0;
+                 dg.eb = c->ab + c->n_ab + o.bn.ab + C0;
+                 dg.emean = c->mean + lv.stat_off + o.in_off + C0;
+                 dg.einvstd = c->invstd + lv.stat_off + o.in_off + C0;
+                 dg.egamma = c->params + o.bn.gamma + C0;
+                 dg.acc_lo = std::max(0, o.acc_lo - C0);
+                 dg.acc_hi = std::max(0, o.acc_hi - C0);
+                 dg.H = lv.H;
+                 dg.W = lv.W;
+                 dg.N = N;
+                 dg.stat_partial = c->stat_partial;
+                 dg.st = lv.st;
+                 return d3_dgl_supported(dg);
+               }()) {
+      // 16-bit MFMA form of the per-layer data gradient into the block's own new channels (dense3.h: D3Dgl)
+      const int64_t so = lv.stat_off + o.in_off + C0;
+      d3_dgl_plan(lv.H, lv.W, &dg);
+      {
+        const double flops = 2.0 * Jn * o.cout * 9.0 * plane * N;
+        const double eb = (double)st_bytes(lv.st);
+        const double bytes = (double)N * plane * (eb * o.cout + (eb + 4.0) * Jn + 4.0 * (dg.acc_hi - dg.acc_lo));
+        ProfScope ps(c, PC_DENSE_DGRAD, flops, bytes, s);
+        RLN_TRY(d3_dgl_launch(dg, c->d3_bwd_np, c->d3_bwd_dt, s));
+      }
+      if (use_tail) {
+        tail.bn_partial = c->stat_partial;
+        tail.bn_rows = d3_dgl_rows(dg);
+        tail.J = Jn;
+        tail.gamma = c->params + o.bn.gamma + C0;
+        tail.dgamma = c->grads + o.bn.gamma + C0;
+        tail.dbeta = c->grads + o.bn.beta + C0;
+        tail.S1 = c->S1 + so;
+        tail.S2 = c->S2 + so;
+      } else {
+        ProfScope psb(c, PC_BN, 0, 0, s);
+        RLN_TRY(bn_bwd_finalize(c->stat_partial, d3_dgl_rows(dg), Jn, c->params + o.bn.gamma + C0,
+                                c->grads + o.bn.gamma + C0, c->grads + o.bn.beta + C0, c->S1 + so, c->S2 + so, s));
+      }
     } else if (Jn > 0) {
       IgemmParams p;
       memset(&p, 0, sizeof(p));
