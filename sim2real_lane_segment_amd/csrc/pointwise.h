@@ -42,6 +42,7 @@ struct GradFinParams {
   const unsigned char* pool_idx;  // [N][C][H][W] or null
   int Hd, Wd;
   int st, yt;  // storage element types of S and of dst (storage.h); G is fp32
+  int vec4;     // set by grad_finalize(): 16-byte path legal (plane % 4 == 0, aligned views)
   void* dst16;  // optional second copy of dst rounded to bf16 (the dense weight gradient's one-part operand), or null
 };
 // returns number of bias_partial rows through *rows

@@ -207,7 +207,24 @@ __global__ __launch_bounds__(256) void grad_finalize_k(const GradFinParams p) {
   const SP<YT> dp = SP<YT>(p.dst) + ((long long)n * p.C + c) * dplane;
   float bsum = 0.f;
   const long long e0 = (long long)blockIdx.x * 1024;
-  if (p.pool_idx == nullptr) {
+  if (p.pool_idx == nullptr && p.vec4) {  // planes of a multiple of 4 elements, 16-byte aligned views: one quad per thread
+    const long long e = e0 + 4 * tid;
+    if (e < dplane) {
+      const float4 x4 = Sp.ld4(e);
+      const float4 g4 = *reinterpret_cast<const float4*>(Gp + e);
+      const float xs[4] = {x4.x, x4.y, x4.z, x4.w}, gs[4] = {g4.x, g4.y, g4.z, g4.w};
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float xh = (xs[r] - mean) * is;
+        v[r] = st_round<YT>(sc * is * (gs[r] - k1 - xh * k2));  // the bias gradient sums what is stored
+      }
+      dp.st4(e, v[0], v[1], v[2], v[3]);
+      if (p.dst16 != nullptr) (SP<ST_BF16>(p.dst16) + ((long long)n * p.C + c) * dplane).st4(e, v[0], v[1], v[2], v[3]);
+      // same summation order per lane as the scalar form is not required: the block sum below is order-fixed
+      bsum = (v[0] + v[1]) + (v[2] + v[3]);
+    }
+  } else if (p.pool_idx == nullptr) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const long long e = e0 + i * 256 + tid;
@@ -261,14 +278,22 @@ int grad_finalize(const GradFinParams& p, int N, long long* rows, hipStream_t s)
   const long long nbx = ((long long)p.Hd * p.Wd + 1023) / 1024;
   if (rows) *rows = nbx * N;
   const dim3 grid((unsigned)nbx, (unsigned)p.C, (unsigned)N);
+  GradFinParams q = p;
+  {
+    const long long plane = (long long)p.H * p.W;
+    auto al = [](const void* a, uintptr_t m) { return (reinterpret_cast<uintptr_t>(a) & m) == 0; };
+    q.vec4 = (p.pool_idx == nullptr && (plane % 4) == 0 && (p.ns % 4) == 0 && al(p.G, 15) &&
+              al(p.S, p.st == ST_BF16 ? 7 : 15) && al(p.dst, p.yt == ST_BF16 ? 7 : 15) && (p.dst16 == nullptr || al(p.dst16, 7)))
+                 ? 1 : 0;
+  }
   if (p.st == ST_BF16 && p.yt == ST_BF16)
-    hipLaunchKernelGGL((grad_finalize_k<ST_BF16, ST_BF16>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((grad_finalize_k<ST_BF16, ST_BF16>), grid, dim3(256), 0, s, q);
   else if (p.st == ST_BF16)
-    hipLaunchKernelGGL((grad_finalize_k<ST_BF16, ST_F32>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((grad_finalize_k<ST_BF16, ST_F32>), grid, dim3(256), 0, s, q);
   else if (p.yt == ST_BF16)
     return -4;
   else
-    hipLaunchKernelGGL((grad_finalize_k<ST_F32, ST_F32>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((grad_finalize_k<ST_F32, ST_F32>), grid, dim3(256), 0, s, q);
   RLN_LAUNCH_CHECK();
 }
 
