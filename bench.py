@@ -39,11 +39,11 @@ CLASS_KERNELS = {
     "dense3_wgrad": ("void rln::d3_wgrad_k<",),
     "dense3_dgrad_pull": ("void rln::d3_pull_k<",),
     "dense_conv3x3_fwd": ("void rln::igemm_k<3, 1, 1, 0,",),
-    "dense_conv3x3_dgrad": ("void rln::dgrad_loop_k<",),
+    "dense_conv3x3_dgrad": ("void rln::d3_dgl_k<", "void rln::dgrad_loop_k<"),
     "dense_conv3x3_wgrad": ("void rln::wgrad_dense_q_k<", "void rln::wgrad_k<3, 1, 1,"),
 }
 # classes that run on the 16-bit MFMA pipe with split operands: products issued per algorithmic multiply-add
-SPLIT_CLASSES = ("dense3_fwd", "dense3_fwd_small", "dense3_wgrad", "dense3_dgrad_pull")
+SPLIT_CLASSES = ("dense3_fwd", "dense3_fwd_small", "dense3_wgrad", "dense3_dgrad_pull")  # (dense_conv3x3_dgrad mixes the 16-bit d3_dgl_k and the exact-fp32 small-level launches)
 
 
 def pmc_traffic(class_name, summary=None):
