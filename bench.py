@@ -445,6 +445,19 @@ def main():
         secondary["storage_" + other] = sec
         del st2, model2, eng2
         torch.cuda.empty_cache()
+        if args.dtype == "f32":
+            # the same step on the exact-fp32 MFMA family only (v_mfma_f32_16x16x4_f32 everywhere): what the split-operand
+            # arithmetic of the headline line is measured against (report an fp32,fp32 line for comparison)
+            model3, eng3 = build("f32", "fp32", "fp32")
+            st3 = TrainStepper(eng3, lr=1e-3, weight_decay=1e-4)
+            n3 = max(5, args.steps // 2)
+            dt3, out3 = timed(st3, n3, 2)
+            secondary["exact_fp32_mfma"] = {"value": round(B * n3 / dt3, 2), "unit": "images/sec", "dtype": "f32",
+                                            "ms_per_step": round(1000.0 * dt3 / n3, 3),
+                                            "final_loss": round(float(out3[0]), 5),
+                                            "dense_arith": "0 parts: exact fp32 MFMA kernels for every convolution"}
+            del st3, model3, eng3
+            torch.cuda.empty_cache()
         if not args.no_inference:
             secondary["inference_480x640"] = inference_bench(dev, build)
 
