@@ -2118,6 +2118,31 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
       }
     }
     const int Jn = pull_new ? 0 : o.cin - C0;  // new channels this layer consumes (per-layer form only)
+    bool use_dgl = false;
+    if (Jn > 0 && dgl16 && !(layer_pull && use_tail)) {  // does the 16-bit looped form cover this geometry?
+      memset(&dg, 0, sizeof(dg));
+      dg.dY = dYj;
+      dg.K = o.cout;
+      dg.wpk = c->d3_packed + c->d3_wb_off[(size_t)k0 + j] + (long long)(C0 / 16) * 5 * c->d3_bwd_np * 64;
+      dg.J = Jn;
+      dg.S = lv.sp(o.in_off + C0);
+      dg.s_ns = (long long)lv.C * plane;
+      dg.cs = (int)plane;
+      dg.G = lv.G + (size_t)(o.in_off + C0) * plane;
+      dg.ea = c->ab + o.bn.ab + C0;
+      dg.eb = c->ab + c->n_ab + o.bn.ab + C0;
+      dg.emean = c->mean + lv.stat_off + o.in_off + C0;
+      dg.einvstd = c->invstd + lv.stat_off + o.in_off + C0;
+      dg.egamma = c->params + o.bn.gamma + C0;
+      dg.acc_lo = std::max(0, o.acc_lo - C0);
+      dg.acc_hi = std::max(0, o.acc_hi - C0);
+      dg.H = lv.H;
+      dg.W = lv.W;
+      dg.N = N;
+      dg.stat_partial = c->stat_partial;
+      dg.st = lv.st;
+      use_dgl = d3_dgl_supported(dg);
+    }
     if (Jn > 0 && layer_pull && use_tail) {
       long long prow = 0;
       const int64_t so = lv.stat_off + o.in_off + C0;
@@ -2130,30 +2155,7 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
       tail.dbeta = c->grads + o.bn.beta + C0;
       tail.S1 = c->S1 + so;
       tail.S2 = c->S2 + so;
-    } else if (Jn > 0 && dgl16 && [&]() -> bool {  // the 16-bit looped form covers this geometry?
-                 memset(&dg, 0, sizeof(dg));
-                 dg.dY = dYj;
-                 dg.K = o.cout;
-                 dg.wpk = c->d3_packed + c->d3_wb_off[(size_t)k0 + j] + (long long)(C0 / 16) * 5 * c->d3_bwd_np * 64;
-                 dg.J = Jn;
-                 dg.S = lv.sp(o.in_off + C0);
-                 dg.s_ns = (long long)lv.C * plane;
-                 dg.cs = (int)plane;
-                 dg.G = lv.G + (size_t)(o.in_off + C0) * plane;
-                 dg.ea = c->ab + o.bn.ab + C0;
-                 dg.eb = c->ab + c->n_ab + o.bn.ab + C0;
-                 dg.emean = c->mean + lv.stat_off + o.in_off + C0;
-                 dg.einvstd = c->invstd + lv.stat_off + o.in_off + C0;
-                 dg.egamma = c->params + o.bn.gamma + C0;
-                 dg.acc_lo = std::max(0, o.acc_lo - C0);
-                 dg.acc_hi = std::max(0, o.acc_hi - C0);
-                 dg.H = lv.H;
-                 dg.W = lv.W;
-                 dg.N = N;
-                 dg.stat_partial = c->stat_partial;
-                 dg.st = lv.st;
-                 return d3_dgl_supported(dg);
-               }()) {
+    } else if (use_dgl) {
       // 16-bit MFMA form of the per-layer data gradient into the block's own new channels (dense3.h: D3Dgl)
       const int64_t so = lv.stat_off + o.in_off + C0;
       d3_dgl_plan(lv.H, lv.W, &dg);
