@@ -86,6 +86,14 @@ struct D3Wgrad {
   int st;          // storage element type of S and dY (storage.h)
   const void* dY16;  // fp32 stacks only: bf16 copy of dY written by grad_finalize (GradFinParams.dst16), or null
   int yt;            // ST_BF16 with st == ST_F32: read dY16 instead of dY (one bf16 part); otherwise ignored
+  // two-layer launch (nl == 2, needs yt == ST_BF16): the secondary layer consumes the first Cin2 <= Cin of the same
+  // input channels with its own BatchNorm table, dY copy and partial slabs
+  int nl;
+  int Cin2;
+  const float* pa2;
+  const float* pb2;
+  const void* dY16_2;
+  float* partial2;  // [nranges][Cout*Cin2*9]
 };
 bool d3_wgrad_supported(const D3Wgrad& p);
 void d3_wgrad_plan(int H, int W, int N, int Cin, D3Wgrad* p);  // fills th, tw, tiles, rg, nchunks, nranges

@@ -533,10 +533,16 @@ __device__ __forceinline__ uint2 lds_tr16(const unsigned char* p) {
 // one-part bf16 operand is rounded once by grad_finalize_k into a 2-byte copy (p.dY16) instead of by every one of the
 // Cin / 16 chunk blocks that re-read the tile -- the dY share of the staged bytes halves; a dY unit is then 8 channels
 // x 8 pixels (one 16-byte load per channel, like every other unit).
-template <int NP, int DT, int ST, int YT>
+// NL = 2: two layers of one block in one launch.  Layer j+1 consumes every input channel of layer j (plus its own 16 new
+// ones), each with its own BatchNorm: the z chunk is LOADED once and converted twice (two z images, two dY tiles, two
+// sets of tap accumulators).  The z loads are the largest share of this kernel's time (ablation in DESIGN.md 4.1e).
+// The primary layer (p.Cin, p.pa, p.dY16, p.partial) is the one with more channels and defines the chunk grid; the
+// secondary (p.Cin2 <= p.Cin, p.pa2, p.dY16_2, p.partial2) takes part in the chunks it has.
+template <int NP, int DT, int ST, int YT, int NL>
 __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
   constexpr bool Y16 = (ST == ST_F32 && YT == ST_BF16);
   static_assert(ST == YT || (Y16 && NP == 1 && DT == D3_BF16), "mixed storage: fp32 stacks with a bf16 dY copy, one bf16 part");
+  static_assert(NL == 1 || Y16, "two-layer launches use the 8-pixel dY units of the bf16 copy");
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool producer = wave >= 4;
@@ -545,10 +551,11 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
   const int PLZ = rows * P * 32;          // one part of the z image
   const int npix = p.th * p.tw;           // 320
   const int PLY = npix * 32;              // one part of the dY image
-  const int ZB = NP * PLZ, YB = NP * PLY; // one buffer each
-  unsigned char* zbuf = smem;             // [2][NP][PLZ]
-  unsigned char* ybuf = smem + 2 * ZB;    // [2][NP][PLY]
-  float* abtab = reinterpret_cast<float*>(smem + 2 * ZB + 2 * YB);  // a[16], b[16] of this chunk
+  const int ZL = NP * PLZ, YL = NP * PLY;  // one layer's images
+  const int ZB = NL * ZL, YB = NL * YL;    // one buffer each
+  unsigned char* zbuf = smem;             // [2][NL][NP][PLZ]
+  unsigned char* ybuf = smem + 2 * ZB;    // [2][NL][NP][PLY]
+  float* abtab = reinterpret_cast<float*>(smem + 2 * ZB + 2 * YB);  // per layer: a[16], b[16] of this chunk
 
   const unsigned lg_id = xcd_logical_block(blockIdx.x, gridDim.x);
   const int chunk = (int)(lg_id % (unsigned)p.nchunks), range = (int)(lg_id / (unsigned)p.nchunks);
@@ -559,22 +566,28 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
   const int t0 = range * per;
   const int nt = max(0, min(total, t0 + per) - t0);
 
-  if (tid < 32) {
-    const int ch = cb + (tid & 15);
-    abtab[tid] = ch < p.Cin ? (tid < 16 ? p.pa[ch] : p.pb[ch]) : 0.f;
+  const bool sec_active = NL == 2 && chunk * 16 < p.Cin2;  // the secondary layer has this chunk (block-uniform)
+  if (tid < 32 * NL) {
+    const int L = tid >> 5, t = tid & 31;
+    const int ch = cb + (t & 15);
+    const float* ta = L ? p.pa2 : p.pa;
+    const float* tb = L ? p.pb2 : p.pb;
+    abtab[tid] = ch < (L ? p.Cin2 : p.Cin) ? (t < 16 ? ta[ch] : tb[ch]) : 0.f;
   }
   if (p.tiles_x == 1) {  // full-width tiles (the 15x20 level: a whole sample per tile): zero padding columns, written once
-    for (int i = tid; i < 2 * NP * rows * 2; i += 768) {
-      const int side = i & 1, r = (i >> 1) % rows, bp = (i >> 1) / rows;  // bp = buffer * NP + part
+    for (int i = tid; i < 2 * NL * NP * rows * 2; i += 768) {
+      const int side = i & 1, r = (i >> 1) % rows, bp = (i >> 1) / rows;  // bp = (buffer * NL + layer) * NP + part
       uint4* z = reinterpret_cast<uint4*>(zbuf + bp * PLZ + (r * P + (side ? p.tw + 1 : 0)) * 32);
       z[0] = make_uint4(0u, 0u, 0u, 0u);
       z[1] = make_uint4(0u, 0u, 0u, 0u);
     }
   }
 
-  f32x4 acc[9];
+  f32x4 acc[NL][9];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int L = 0; L < NL; ++L)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[L][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (producer) {
     // All 8 producer waves work on EVERY tile: thread -> one staging unit (8 channels x 4 pixels, or a halo pair):
@@ -589,7 +602,7 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
     const int nqg = (nq + qpg - 1) / qpg;
     const int nrg = (rows + p.rg - 1) >> rgs;
     const int kind = ptid < 256 ? 0 : (ptid < 416 ? 1 : 2);
-    int u_r = 0, u_q = 0, u_o = 0, u_lds = 0, h_side = 0;
+    int u_r = 0, u_q = 0, u_o = 0, u_lds = 0, h_side = 0, y_layer = 0;
     bool u_ex = false;
     if (kind == 0) {
       const int lu = ptid;
@@ -601,14 +614,19 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
       u_ex = (R < nrg) && (u_r < rows) && (u_q < nq);
       u_lds = ((u_ex ? u_r : 0) * P + 1 + 4 * (u_ex ? u_q : 0)) * 32 + u_o * 16;
     } else if (kind == 1) {
-      const int yu = ptid - 256;
+      int yu = ptid - 256;
+      const int nqy = Y16 ? (p.tw >> 3) : nq;  // units per row: 8 pixels each with the bf16 copy
+      if constexpr (NL == 2) {  // the second layer's dY units follow the first layer's
+        const int nyu = 2 * p.th * nqy;
+        y_layer = yu >= nyu ? 1 : 0;
+        yu -= y_layer * nyu;
+      }
       u_o = yu & 1;
       const int y2 = yu >> 1;
-      const int nqy = Y16 ? (p.tw >> 3) : nq;  // units per row: 8 pixels each with the bf16 copy
       u_r = y2 / nqy;
       u_q = y2 - u_r * nqy;
       u_ex = u_r < p.th;
-      u_lds = ((u_ex ? u_r : 0) * p.tw + (Y16 ? 8 : 4) * u_q) * 32 + u_o * 16;
+      u_lds = y_layer * YL + ((u_ex ? u_r : 0) * p.tw + (Y16 ? 8 : 4) * u_q) * 32 + u_o * 16;
     } else {
       const int hu = ptid - 416;
       u_o = hu & 3;  // channel quad
@@ -629,7 +647,8 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
     typedef typename SRaw<ST>::r4 Raw4;  // every unit loads 8 x Raw4 (with Y16 a dY unit's 16 bytes hold 8 bf16 pixels)
     const SP<ST> kbase(kind == 1 ? p.dY : p.S);
     const long long kns = kind == 1 ? (long long)p.Cout * p.cs : p.ns;
-    const unsigned char* kbytes = reinterpret_cast<const unsigned char*>(kind == 1 ? p.dY16 : (const void*)p.S);
+    const unsigned char* kbytes =
+        reinterpret_cast<const unsigned char*>(kind == 1 ? (y_layer ? p.dY16_2 : p.dY16) : (const void*)p.S);
     const int kes = (Y16 && kind == 1) ? 2 : 4;  // bytes per element of this thread's operand
     Raw4 regA[8], regB[8];
     bool okA = false, okB = false;
@@ -686,17 +705,23 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
       if (p.dbg & 2) return;
 #endif
       if (kind == 2) {
-        float zv[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float x = h_side ? reg[k].x : reg[k].w;
-          zv[k] = okf ? fmaxf(fmaf(abtab[4 * u_o + k], x, abtab[16 + 4 * u_o + k]), 0.f) : 0.f;
+        for (int L = 0; L < NL; ++L) {
+          if (L == 1 && !sec_active) break;  // block-uniform
+          const float* ab = abtab + 32 * L;
+          float zv[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float x = h_side ? reg[k].x : reg[k].w;
+            zv[k] = okf ? fmaxf(fmaf(ab[4 * u_o + k], x, ab[16 + 4 * u_o + k]), 0.f) : 0.f;
+          }
+          unsigned pa[NP], pb2[NP];
+          split2<DT, NP>(zv[0], zv[1], pa);
+          split2<DT, NP>(zv[2], zv[3], pb2);
+#pragma unroll
+          for (int pt = 0; pt < NP; ++pt)
+            *reinterpret_cast<uint2*>(zb + L * ZL + pt * PLZ + u_lds) = make_uint2(pa[pt], pb2[pt]);
         }
-        unsigned pa[NP], pb2[NP];
-        split2<DT, NP>(zv[0], zv[1], pa);
-        split2<DT, NP>(zv[2], zv[3], pb2);
-#pragma unroll
-        for (int pt = 0; pt < NP; ++pt) *reinterpret_cast<uint2*>(zb + pt * PLZ + u_lds) = make_uint2(pa[pt], pb2[pt]);
         return;
       }
       if constexpr (Y16) {
@@ -724,13 +749,17 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
         }
       }
       // kind 0: z = relu(a*x + b) of 8 channels x 4 pixels; kind 1: dY as it is (zero beyond Cout); zero outside
+#pragma unroll
+      for (int L = 0; L < NL; ++L) {
+      if (L == 1 && (!sec_active || kind != 0)) break;  // the second conversion of the same z chunk (block-uniform / kind 0)
+      const float* ab = abtab + 32 * L;
       float av[8], bv[8];
 #pragma unroll
       for (int cc = 0; cc < 8; ++cc) {
-        av[cc] = kind == 0 ? abtab[u_o * 8 + cc] : ((u_o * 8 + cc < p.Cout) ? 1.f : 0.f);
-        bv[cc] = kind == 0 ? abtab[16 + u_o * 8 + cc] : 0.f;
+        av[cc] = kind == 0 ? ab[u_o * 8 + cc] : ((u_o * 8 + cc < p.Cout) ? 1.f : 0.f);
+        bv[cc] = kind == 0 ? ab[16 + u_o * 8 + cc] : 0.f;
       }
-      unsigned char* dst = (kind == 0 ? zb : yb) + u_lds;
+      unsigned char* dst = (kind == 0 ? zb + L * ZL : yb) + u_lds;
       const int plane = kind == 0 ? PLZ : PLY;
 #pragma unroll
       for (int px = 0; px < 4; ++px) {
@@ -751,6 +780,7 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
         for (int pt = 0; pt < NP; ++pt)
           *reinterpret_cast<uint4*>(dst + pt * plane + px * 32) =
               make_uint4(parts[0][pt], parts[1][pt], parts[2][pt], parts[3][pt]);
+      }
       }
     };
     __syncthreads();  // affine table
@@ -812,22 +842,27 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
       // a K-step a wave does not own runs with a zero dY fragment (adds nothing) so that all four waves share one code path
       constexpr int DEPTH = 3, RING = DEPTH + 1;
       const int STEPS = nks * 9;  // wave-uniform: 27 (waves 0, 1) or 18 (waves 2, 3)
-      uint4 af[2][NP], bfr[RING][NP];
-      auto load_a = [&](int k, uint4 (&dst)[NP]) __attribute__((always_inline)) {
+      uint4 af[2][NL][NP], bfr[RING][NL][NP];
+      auto load_a = [&](int k, uint4 (&dst)[NL][NP]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int pt = 0; pt < NP; ++pt) {
-          const uint2 lo = lds_tr16(yb + pt * PLY + ya[k][0]), hi = lds_tr16(yb + pt * PLY + ya[k][1]);
-          dst[pt] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        }
+        for (int L = 0; L < NL; ++L)
+#pragma unroll
+          for (int pt = 0; pt < NP; ++pt) {
+            const uint2 lo = lds_tr16(yb + L * YL + pt * PLY + ya[k][0]), hi = lds_tr16(yb + L * YL + pt * PLY + ya[k][1]);
+            dst[L][pt] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          }
       };
-      auto load_b = [&](int st, uint4 (&dst)[NP]) __attribute__((always_inline)) {
+      auto load_b = [&](int st, uint4 (&dst)[NL][NP]) __attribute__((always_inline)) {
         const int k = st / 9, t = st - k * 9;
         const int toff = ((t / 3 - 1) * P + (t % 3 - 1)) * 32;
 #pragma unroll
-        for (int pt = 0; pt < NP; ++pt) {
-          const uint2 lo = lds_tr16(zb + pt * PLZ + za[k][0] + toff), hi = lds_tr16(zb + pt * PLZ + za[k][1] + toff);
-          dst[pt] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        }
+        for (int L = 0; L < NL; ++L)
+#pragma unroll
+          for (int pt = 0; pt < NP; ++pt) {
+            const uint2 lo = lds_tr16(zb + L * ZL + pt * PLZ + za[k][0] + toff),
+                        hi = lds_tr16(zb + L * ZL + pt * PLZ + za[k][1] + toff);
+            dst[L][pt] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          }
       };
       load_a(0, af[0]);
 #pragma unroll
@@ -842,7 +877,8 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
         if (st < STEPS) {  // wave-uniform
           if (st + DEPTH < KS * 9) load_b(st + DEPTH, bfr[(st + DEPTH) % RING]);  // past the wave's steps: clamped, unused
           if (t == 9 - DEPTH && k + 1 < KS) load_a(k + 1, af[(k + 1) & 1]);
-          acc[t] = mfma_split<DT, NP>(af[k & 1], bfr[st % RING], acc[t]);
+#pragma unroll
+          for (int L = 0; L < NL; ++L) acc[L][t] = mfma_split<DT, NP>(af[k & 1][L], bfr[st % RING][L], acc[L][t]);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -852,25 +888,32 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
 
   // ---- reduce the four consumer waves' tap accumulators through LDS and write this block's slab piece ----
   __syncthreads();
-  float4* red = reinterpret_cast<float4*>(smem);  // [4 waves][9 taps][64 lanes]
+  constexpr int NT = 9 * NL;
+  float4* red = reinterpret_cast<float4*>(smem);  // [4 waves][NL x 9 taps][64 lanes]
   if (!producer) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) red[(wave * 9 + t) * 64 + lane] = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+    for (int L = 0; L < NL; ++L)
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        red[(wave * NT + L * 9 + t) * 64 + lane] = make_float4(acc[L][t][0], acc[L][t][1], acc[L][t][2], acc[L][t][3]);
   }
   __syncthreads();
-  for (int e = tid; e < 9 * 64; e += 768) {
-    const int t = e >> 6, l = e & 63;
-    const float4 a0 = red[(0 * 9 + t) * 64 + l], a1 = red[(1 * 9 + t) * 64 + l], a2 = red[(2 * 9 + t) * 64 + l],
-                 a3 = red[(3 * 9 + t) * 64 + l];
+  for (int e = tid; e < NT * 64; e += 768) {
+    const int lt = e >> 6, l = e & 63;
+    const int L = lt / 9, t = lt - L * 9;
+    if (L == 1 && !sec_active) continue;
+    const float4 a0 = red[(0 * NT + lt) * 64 + l], a1 = red[(1 * NT + lt) * 64 + l], a2 = red[(2 * NT + lt) * 64 + l],
+                 a3 = red[(3 * NT + lt) * 64 + l];
     const float v[4] = {a0.x + a1.x + a2.x + a3.x, a0.y + a1.y + a2.y + a3.y, a0.z + a1.z + a2.z + a3.z,
                         a0.w + a1.w + a2.w + a3.w};
     const int c = cb + (l & 15);  // D[row = 4*(l>>4) + r = output channel o][col = l & 15 = input channel]
-    if (c < p.Cin && c >= chunk * 16) {
-      float* dst = p.partial + (long long)range * p.Cout * p.Cin * 9;
+    const int cin = L ? p.Cin2 : p.Cin;
+    if (c < cin && c >= chunk * 16) {
+      float* dst = (L ? p.partial2 : p.partial) + (long long)range * p.Cout * cin * 9;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int o = 4 * (l >> 4) + r;
-        if (o < p.Cout) dst[((long long)o * p.Cin + c) * 9 + t] = v[r];
+        if (o < p.Cout) dst[((long long)o * cin + c) * 9 + t] = v[r];
       }
     }
   }
@@ -907,12 +950,12 @@ void d3_wgrad_plan(int H, int W, int N, int Cin, D3Wgrad* p) {
   p->nranges = (int)((total + per - 1) / per);  // no empty ranges
 }
 
-template <int NP, int DT, int ST = ST_F32, int YT = ST>
+template <int NP, int DT, int ST = ST_F32, int YT = ST, int NL = 1>
 static int d3_wgrad_launch_t(const D3Wgrad& p, hipStream_t s) {
   const int P = p.tw + 3, rows = p.th + 2;
-  const size_t lds = (size_t)2 * NP * rows * P * 32 + (size_t)2 * NP * p.th * p.tw * 32 + 128;
-  if (lds > 160 * 1024 || lds < 4 * 9 * 64 * 16) return -4;
-  auto kern = d3_wgrad_k<NP, DT, ST, YT>;
+  const size_t lds = (size_t)2 * NL * NP * rows * P * 32 + (size_t)2 * NL * NP * p.th * p.tw * 32 + 128 * NL;
+  if (lds > 160 * 1024 || lds < (size_t)4 * 9 * NL * 64 * 16) return -4;
+  auto kern = d3_wgrad_k<NP, DT, ST, YT, NL>;
   static DevOnce attr_once;
   if (attr_once.first()) {
     const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -944,8 +987,16 @@ int d3_wgrad_launch(const D3Wgrad& p, int np, int dt, hipStream_t s) {
     if (np != 1 || dt != D3_BF16 || p.dY16 == nullptr || (p.tw & 7) || (reinterpret_cast<uintptr_t>(p.dY16) & 15) ||
         (((long long)p.cs * 2) & 15) || p.th * (p.tw >> 3) * 2 > 160)
       return -4;
+    if (p.nl == 2) {  // two layers of a block in one launch (see d3_wgrad_k)
+      if (p.dY16_2 == nullptr || p.partial2 == nullptr || p.pa2 == nullptr || p.pb2 == nullptr || p.Cin2 < 16 ||
+          p.Cin2 > p.Cin || (p.Cin & 15) || (p.Cin2 & 15) || (reinterpret_cast<uintptr_t>(p.dY16_2) & 15) ||
+          p.th * (p.tw >> 3) * 4 > 160)
+        return -4;
+      return d3_wgrad_launch_t<1, D3_BF16, ST_F32, ST_BF16, 2>(p, s);
+    }
     return d3_wgrad_launch_t<1, D3_BF16, ST_F32, ST_BF16>(p, s);
   }
+  if (p.nl == 2) return -4;
   if (dt == D3_BF16) {
     if (np == 1) return d3_wgrad_launch_t<1, D3_BF16>(p, s);
     if (np == 2) return d3_wgrad_launch_t<2, D3_BF16>(p, s);

@@ -164,7 +164,9 @@ struct rln_ctx {
   hipEvent_t ev_wg[2] = {nullptr, nullptr};  // last weight-gradient reading dY[buf] finished (side stream)
   bool wg_pending[2] = {false, false};
   float* dYbuf[2] = {nullptr, nullptr};
-  void* dy16 = nullptr;  // bf16 copy of a dense layer's finalised output gradient (the weight gradient's one-part operand)
+  void* dy16 = nullptr;  // bf16 copies of dense layers' finalised output gradients (the weight gradient's one-part operand):
+  size_t dy16_half = 0;  // two buffers of this many bytes, by layer parity (two-layer weight-gradient launches)
+  float* wpartial2 = nullptr;  // slabs of the secondary layer of a two-layer launch
   int dy_flip = 0;
   bool use_side = false;
   // forward/backward hand-over state
@@ -652,8 +654,9 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
   float* fsplit = cv.take<float>(fs_max);
   float* dY = with_bwd ? cv.take<float>(dy_max) : nullptr;
   float* dY2 = with_bwd ? cv.take<float>(dy_max) : nullptr;
-  float* dy16 = with_bwd ? cv.take<float>((dy_max + 1) / 2) : nullptr;  // dy_max bf16 elements
+  float* dy16 = with_bwd ? cv.take<float>(2 * ((dy_max + 1) / 2)) : nullptr;  // 2 x dy_max bf16 elements (layer parity)
   float* wpartial = with_bwd ? cv.take<float>(wp_max) : nullptr;
+  float* wpartial2 = with_bwd ? cv.take<float>(wp_max) : nullptr;
   float* bpartial = with_bwd ? cv.take<float>(bp_max) : nullptr;
   float* glin = with_bwd ? cv.take<float>((size_t)n * c->cfg.n_classes * hw0) : nullptr;
   // split-operand dense kernels: packed weight fragments + descriptor tables
@@ -801,7 +804,9 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
     c->dYbuf[0] = dY;
     c->dYbuf[1] = dY2;
     c->dy16 = dy16;
+    c->dy16_half = (size_t)((dy_max + 1) / 2) * sizeof(float);
     c->wpartial = wpartial;
+    c->wpartial2 = wpartial2;
     c->bpartial = bpartial;
     c->glin = glin;
     c->dyblk = dyblk;
@@ -2029,6 +2034,10 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
                      rln_env("RLN_NO_DGL") == nullptr;
   D3Dgl dg;
 
+  // Two-layer weight-gradient launches (dense3.h: D3Wgrad.nl): layer j+1 is deferred until layer j's dY is finalised,
+  // then ONE launch loads every z chunk once for both.  pend_j = the deferred layer (or -1).
+  int pend_j = -1;
+  static const bool no_pair = rln_env("RLN_NO_WG_PAIR") != nullptr;
   for (int j = L - 1; j >= 0; --j) {
     const Op& o = c->ops[(size_t)k0 + j];
     long long rows = 0;
@@ -2044,8 +2053,8 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
     const bool use_dy16 = !no_dy16 && lv.st == ST_F32 && c->d3_bwd_np > 0 && c->d3_bwd_dt == D3_BF16 && o.cout <= 16 &&
                           wgrad_parts(c, (long long)N * lv.H * lv.W) == 1 && (lv.W % 40) == 0 && c->dy16 != nullptr &&
                           ((lv.H * lv.W) % 8) == 0;
-    RLN_TRY(finalize_grad_range(c, o.dst_level, o.out_off, o.cout, nscale, &rows, s, dYj, -1,
-                                use_dy16 ? c->dy16 : nullptr));
+    void* dy16_j = use_dy16 ? static_cast<unsigned char*>(c->dy16) + (size_t)(j & 1) * c->dy16_half : nullptr;
+    RLN_TRY(finalize_grad_range(c, o.dst_level, o.out_off, o.cout, nscale, &rows, s, dYj, -1, dy16_j));
     // the layer's three small reductions (bias rows, weight slabs, BatchNorm-backward sums of its new-channel data
     // gradient) run as ONE launch at the end of the iteration when the weight gradient went through d3_wgrad_k
     DenseTail tail;
@@ -2091,28 +2100,67 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
       if (d3_wgrad_supported(g)) {  // transposed-read 16-bit MFMA kernel
         d3_wgrad_plan(lv.H, lv.W, N, o.cin, &g);
         if (use_dy16 && (g.tw % 8) == 0) {
-          g.dY16 = c->dy16;
+          g.dY16 = dy16_j;
           g.yt = ST_BF16;
         }
 #ifdef RLN_DIAG
         if (rln_env("RLN_D3_DBG")) g.dbg = atoi(rln_env("RLN_D3_DBG"));
 #endif
-        {
+        const bool pairable = !no_pair && g.yt == ST_BF16 && (o.cin % 16) == 0 && gr == 16 && o.cout == 16 &&
+                              c->wpartial2 != nullptr;
+        use_tail = true;
+        tail.w_len = 0;  // no weight slabs in this iteration unless set below
+        if (pairable && pend_j < 0 && j >= 1 && (c->ops[(size_t)k0 + j - 1].cin % 16) == 0) {
+          pend_j = j;  // launched together with layer j-1
+        } else if (pairable && pend_j == j + 1) {
+          const Op& ob = c->ops[(size_t)k0 + j + 1];  // primary: the deferred layer (16 more input channels)
+          D3Wgrad g2 = g;
+          d3_wgrad_plan(lv.H, lv.W, N, ob.cin, &g2);
+          g2.Cin = ob.cin;
+          g2.pa = c->ab + ob.bn.ab;
+          g2.pb = c->ab + c->n_ab + ob.bn.ab;
+          g2.dY = c->dyblk[(size_t)j + 1];
+          g2.dY16 = static_cast<unsigned char*>(c->dy16) + (size_t)((j + 1) & 1) * c->dy16_half;
+          g2.partial = c->wpartial;
+          g2.nl = 2;
+          g2.Cin2 = o.cin;
+          g2.pa2 = g.pa;
+          g2.pb2 = g.pb;
+          g2.dY16_2 = dy16_j;
+          g2.partial2 = c->wpartial2;
+          {
+            const double wflops = 2.0 * o.cout * ((double)o.cin + ob.cin) * 9.0 * plane * N;
+            const double wbytes = (double)st_bytes(lv.st) * N * (2.0 * o.cout + o.cin + ob.cin) * plane;
+            ProfScope ps(c, PC_D3_WGRAD, wflops, wbytes, s);
+            RLN_TRY(d3_wgrad_launch(g2, 1, c->d3_bwd_dt, s));
+          }
+          {  // the deferred layer's slabs
+            const long long wsize_b = (long long)ob.cout * ob.cin * 9;
+            ProfScope ps(c, PC_REDUCE, 0, 4.0 * (g2.nranges + 1) * wsize_b, s);
+            RLN_TRY(reduce_rows(c->wpartial, g2.nranges, wsize_b, c->grads + ob.conv.w, s));
+          }
+          pend_j = -1;
+          tail.w_src = c->wpartial2;
+          tail.w_rows = g2.nranges;
+          tail.w_len = w.wsize;
+          tail.w_dst = c->grads + o.conv.w;
+        } else {
+          if (pend_j >= 0) return fail(RLN_ERR_STATE, "a deferred dense weight gradient was left behind (layer %d)", pend_j);
           const double wflops = 2.0 * o.cout * o.cin * 9.0 * plane * N;
           const double wbytes = (double)st_bytes(lv.st) * N * ((double)o.cout + o.cin) * plane;
           ProfScope ps(c, PC_D3_WGRAD, wflops, wbytes, s);
           RLN_TRY(d3_wgrad_launch(g, wgrad_parts(c, (long long)N * lv.H * lv.W), c->d3_bwd_dt, s));
+          tail.w_src = c->wpartial;
+          tail.w_rows = g.nranges;
+          tail.w_len = w.wsize;
+          tail.w_dst = c->grads + o.conv.w;
         }
-        use_tail = true;
-        tail.w_src = c->wpartial;
-        tail.w_rows = g.nranges;
-        tail.w_len = w.wsize;
-        tail.w_dst = c->grads + o.conv.w;
         tail.b_src = c->bpartial;
         tail.b_rows = rows;
         tail.b_len = o.cout;
         tail.b_dst = c->grads + o.conv.b;
       } else {
+        if (pend_j >= 0) return fail(RLN_ERR_STATE, "a deferred dense weight gradient was left behind (layer %d)", pend_j);
         RLN_TRY(reduce_rows(c->bpartial, rows, o.cout, c->grads + o.conv.b, s));
         RLN_TRY(run_wgrad(c, WG_DENSE3, w, o.cout, o.cin, o.conv.w, s));
       }
@@ -2252,6 +2300,7 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
       RLN_TRY(dense_tail(tail, s));
     }
   }
+  if (pend_j >= 0) return fail(RLN_ERR_STATE, "a deferred dense weight gradient was left behind (layer %d)", pend_j);
   // input channels [0, C0): all layers at once (passes of at most D3_LMAX layers)
   const Op& last = c->ops[(size_t)k1];
   for (int j0 = L - 1, pass = 0; j0 >= 0; j0 -= D3_LMAX, ++pass) {
