@@ -89,6 +89,7 @@ struct D3Wgrad {
   // two-layer launch (nl == 2, needs yt == ST_BF16): the secondary layer consumes the first Cin2 <= Cin of the same
   // input channels with its own BatchNorm table, dY copy and partial slabs
   int nl;
+  int z8;          // bf16 stacks: 8-pixel units (16-byte loads) for z, dY (= dY16 / dY16_2, the bf16 dY buffers) and halo
   int Cin2;
   const float* pa2;
   const float* pb2;

@@ -538,11 +538,15 @@ __device__ __forceinline__ uint2 lds_tr16(const unsigned char* p) {
 // sets of tap accumulators).  The z loads are the largest share of this kernel's time (ablation in DESIGN.md 4.1e).
 // The primary layer (p.Cin, p.pa, p.dY16, p.partial) is the one with more channels and defines the chunk grid; the
 // secondary (p.Cin2 <= p.Cin, p.pa2, p.dY16_2, p.partial2) takes part in the chunks it has.
-template <int NP, int DT, int ST, int YT, int NL>
+// Z8 (bf16 stacks): every unit is 8 pixels wide -- 16-byte loads of 8 bf16 pixels for z, dY and the halo alike -- which
+// frees the thread slots a second layer's dY tile needs (the 4-pixel form has no room for NL = 2).
+template <int NP, int DT, int ST, int YT, int NL, bool Z8>
 __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
   constexpr bool Y16 = (ST == ST_F32 && YT == ST_BF16);
+  constexpr bool B16 = Y16 || Z8;  // byte-addressed 16-byte loads in every thread, 8-pixel dY units
   static_assert(ST == YT || (Y16 && NP == 1 && DT == D3_BF16), "mixed storage: fp32 stacks with a bf16 dY copy, one bf16 part");
-  static_assert(NL == 1 || Y16, "two-layer launches use the 8-pixel dY units of the bf16 copy");
+  static_assert(!Z8 || (ST == ST_BF16 && YT == ST_BF16 && NP == 1 && DT == D3_BF16), "8-pixel units: bf16 stacks, one bf16 part");
+  static_assert(NL == 1 || B16, "two-layer launches use the 8-pixel dY units");
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool producer = wave >= 4;
@@ -604,7 +608,14 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
     const int kind = ptid < 256 ? 0 : (ptid < 416 ? 1 : 2);
     int u_r = 0, u_q = 0, u_o = 0, u_lds = 0, h_side = 0, y_layer = 0;
     bool u_ex = false;
-    if (kind == 0) {
+    if (kind == 0 && Z8) {  // z unit = (octet, row, 8-pixel group)
+      const int lu = ptid, nq8 = p.tw >> 3;
+      u_o = lu & 1;
+      u_r = (lu >> 1) / nq8;
+      u_q = (lu >> 1) - u_r * nq8;
+      u_ex = u_r < rows;
+      u_lds = ((u_ex ? u_r : 0) * P + 1 + 8 * (u_ex ? u_q : 0)) * 32 + u_o * 16;
+    } else if (kind == 0) {
       const int lu = ptid;
       u_o = lu & 1;
       const int rr = (lu >> 1) & (p.rg - 1), qq = (lu >> (1 + rgs)) & (qpg - 1), u = lu >> 3;
@@ -615,7 +626,7 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
       u_lds = ((u_ex ? u_r : 0) * P + 1 + 4 * (u_ex ? u_q : 0)) * 32 + u_o * 16;
     } else if (kind == 1) {
       int yu = ptid - 256;
-      const int nqy = Y16 ? (p.tw >> 3) : nq;  // units per row: 8 pixels each with the bf16 copy
+      const int nqy = B16 ? (p.tw >> 3) : nq;  // units per row: 8 pixels each with a 2-byte dY
       if constexpr (NL == 2) {  // the second layer's dY units follow the first layer's
         const int nyu = 2 * p.th * nqy;
         y_layer = yu >= nyu ? 1 : 0;
@@ -626,7 +637,7 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
       u_r = y2 / nqy;
       u_q = y2 - u_r * nqy;
       u_ex = u_r < p.th;
-      u_lds = y_layer * YL + ((u_ex ? u_r : 0) * p.tw + (Y16 ? 8 : 4) * u_q) * 32 + u_o * 16;
+      u_lds = y_layer * YL + ((u_ex ? u_r : 0) * p.tw + (B16 ? 8 : 4) * u_q) * 32 + u_o * 16;
     } else {
       const int hu = ptid - 416;
       u_o = hu & 3;  // channel quad
@@ -644,12 +655,13 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
       const int ch = kind == 0 ? cb + u_o * 8 + cc : (kind == 1 ? min(u_o * 8 + cc, p.Cout - 1) : cb + 4 * u_o + (cc & 3));
       choff[cc] = ch * p.cs;
     }
-    typedef typename SRaw<ST>::r4 Raw4;  // every unit loads 8 x Raw4 (with Y16 a dY unit's 16 bytes hold 8 bf16 pixels)
+    // every unit loads 8 x Raw4 (Y16: a dY unit's 16 bytes hold 8 bf16 pixels; Z8: every unit's)
+    typedef typename std::conditional<Z8, uint4, typename SRaw<ST>::r4>::type Raw4;
     const SP<ST> kbase(kind == 1 ? p.dY : p.S);
     const long long kns = kind == 1 ? (long long)p.Cout * p.cs : p.ns;
     const unsigned char* kbytes =
         reinterpret_cast<const unsigned char*>(kind == 1 ? (y_layer ? p.dY16_2 : p.dY16) : (const void*)p.S);
-    const int kes = (Y16 && kind == 1) ? 2 : 4;  // bytes per element of this thread's operand
+    const int kes = (Z8 || (Y16 && kind == 1)) ? 2 : 4;  // bytes per element of this thread's operand
     Raw4 regA[8], regB[8];
     bool okA = false, okB = false;
     // tiles are requested strictly in order t0, t0+1, ...: a cursor replaces two integer divisions per request
@@ -668,19 +680,19 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
       bool ok;
       if (kind == 0) {
         iy = gy0 - 1 + u_r;
-        ix = gx0 + 4 * u_q;
+        ix = gx0 + (Z8 ? 8 : 4) * u_q;
         ok = u_ex && iy >= 0 && iy < p.H && ix < p.W;
       } else if (kind == 1) {
         iy = gy0 + u_r;
-        ix = gx0 + (Y16 ? 8 : 4) * u_q;
+        ix = gx0 + (B16 ? 8 : 4) * u_q;
         ok = u_ex && iy < p.H && ix < p.W;
       } else {  // halo pixel: the aligned quad that holds it (left: last element of the quad, right: first)
         iy = gy0 - 1 + u_r;
         const int hx = h_side ? gx0 + p.tw : gx0 - 1;
         ok = u_ex && iy >= 0 && iy < p.H && hx >= 0 && hx < p.W;
-        ix = h_side ? hx : hx - 3;
+        ix = h_side ? hx : hx - (Z8 ? 7 : 3);  // the aligned group that holds it (left: its last element, right: its first)
       }
-      if constexpr (Y16) {  // one byte-addressed form for both element sizes: the same 8 dwordx4 loads in every thread
+      if constexpr (B16) {  // one byte-addressed form for both element sizes: the same 8 dwordx4 loads in every thread
         const unsigned char* srcb = kbytes + ((long long)n * kns + (ok ? iy * p.W + ix : 0)) * kes;
 #pragma unroll
         for (int cc = 0; cc < 8; ++cc) reg[cc] = *reinterpret_cast<const Raw4*>(srcb + (long long)choff[cc] * kes);
@@ -696,8 +708,11 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
     };
     auto commit = [&](int buf, const Raw4 (&rawreg)[8], bool okf) __attribute__((always_inline)) {
       float4 reg[8];
+      if constexpr (!Z8) {
 #pragma unroll
-      for (int cc = 0; cc < 8; ++cc) reg[cc] = SRaw<ST>::w4(rawreg[cc]);
+        for (int cc = 0; cc < 8; ++cc) reg[cc] = SRaw<ST>::w4(rawreg[cc]);
+      }
+      auto bits = [](auto v) __attribute__((always_inline)) { return __builtin_bit_cast(unsigned, v); };
       unsigned char* zb = zbuf + buf * ZB;
       unsigned char* yb = ybuf + buf * YB;
       if (!u_ex) return;
@@ -712,7 +727,9 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
           float zv[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const float x = h_side ? reg[k].x : reg[k].w;
+            float x;
+            if constexpr (Z8) x = h_side ? bf16_lo(bits(rawreg[k].x)) : bf16_hi(bits(rawreg[k].w));
+            else x = h_side ? reg[k].x : reg[k].w;
             zv[k] = okf ? fmaxf(fmaf(ab[4 * u_o + k], x, ab[16 + 4 * u_o + k]), 0.f) : 0.f;
           }
           unsigned pa[NP], pb2[NP];
@@ -724,16 +741,16 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
         }
         return;
       }
-      if constexpr (Y16) {
+      if constexpr (B16) {
         if (kind == 1) {  // 8 channels x 8 bf16 pixels, already rounded: interleave the channels per pixel
           unsigned wv[8][4];
 #pragma unroll
           for (int cc = 0; cc < 8; ++cc) {
             const bool cv = okf && (u_o * 8 + cc < p.Cout);
-            wv[cc][0] = cv ? __builtin_bit_cast(unsigned, rawreg[cc].x) : 0u;
-            wv[cc][1] = cv ? __builtin_bit_cast(unsigned, rawreg[cc].y) : 0u;
-            wv[cc][2] = cv ? __builtin_bit_cast(unsigned, rawreg[cc].z) : 0u;
-            wv[cc][3] = cv ? __builtin_bit_cast(unsigned, rawreg[cc].w) : 0u;
+            wv[cc][0] = cv ? bits(rawreg[cc].x) : 0u;
+            wv[cc][1] = cv ? bits(rawreg[cc].y) : 0u;
+            wv[cc][2] = cv ? bits(rawreg[cc].z) : 0u;
+            wv[cc][3] = cv ? bits(rawreg[cc].w) : 0u;
           }
 #pragma unroll
           for (int px = 0; px < 8; ++px) {
@@ -747,6 +764,32 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
           }
           return;
         }
+      }
+      if constexpr (Z8) {  // kind 0: z = relu(a*x + b) of 8 channels x 8 bf16 pixels, once per layer of the launch
+#pragma unroll
+        for (int L = 0; L < NL; ++L) {
+          if (L == 1 && !sec_active) break;
+          const float* ab = abtab + 32 * L;
+          float av[8], bv[8];
+#pragma unroll
+          for (int cc = 0; cc < 8; ++cc) {
+            av[cc] = ab[u_o * 8 + cc];
+            bv[cc] = ab[16 + u_o * 8 + cc];
+          }
+          unsigned char* dst = zb + L * ZL + u_lds;
+#pragma unroll
+          for (int px = 0; px < 8; ++px) {
+            unsigned parts[4][NP];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float x0 = SRaw<ST_BF16>::q(rawreg[2 * k], px), x1 = SRaw<ST_BF16>::q(rawreg[2 * k + 1], px);
+              const float z0 = fmaxf(fmaf(av[2 * k], x0, bv[2 * k]), 0.f), z1 = fmaxf(fmaf(av[2 * k + 1], x1, bv[2 * k + 1]), 0.f);
+              split2<DT, NP>(okf ? z0 : 0.f, okf ? z1 : 0.f, parts[k]);
+            }
+            *reinterpret_cast<uint4*>(dst + px * 32) = make_uint4(parts[0][0], parts[1][0], parts[2][0], parts[3][0]);
+          }
+        }
+        return;
       }
       // kind 0: z = relu(a*x + b) of 8 channels x 4 pixels; kind 1: dY as it is (zero beyond Cout); zero outside
 #pragma unroll
@@ -950,12 +993,12 @@ void d3_wgrad_plan(int H, int W, int N, int Cin, D3Wgrad* p) {
   p->nranges = (int)((total + per - 1) / per);  // no empty ranges
 }
 
-template <int NP, int DT, int ST = ST_F32, int YT = ST, int NL = 1>
+template <int NP, int DT, int ST = ST_F32, int YT = ST, int NL = 1, bool Z8 = false>
 static int d3_wgrad_launch_t(const D3Wgrad& p, hipStream_t s) {
   const int P = p.tw + 3, rows = p.th + 2;
   const size_t lds = (size_t)2 * NL * NP * rows * P * 32 + (size_t)2 * NL * NP * p.th * p.tw * 32 + 128 * NL;
   if (lds > 160 * 1024 || lds < (size_t)4 * 9 * NL * 64 * 16) return -4;
-  auto kern = d3_wgrad_k<NP, DT, ST, YT, NL>;
+  auto kern = d3_wgrad_k<NP, DT, ST, YT, NL, Z8>;
   static DevOnce attr_once;
   if (attr_once.first()) {
     const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -981,6 +1024,21 @@ int d3_wgrad_launch(const D3Wgrad& p, int np, int dt, hipStream_t s) {
   }
   if (p.st == ST_BF16) {
     if (np != 1 || dt != D3_BF16) return -4;
+    if (p.z8) {  // 8-pixel units everywhere (see d3_wgrad_k): needed for, and used with, two-layer launches
+      const int rows = p.th + 2, nq8 = p.tw >> 3;
+      if ((p.tw & 7) || (p.W & 7) || 2 * rows * nq8 > 256 || rows * 8 > 96 || p.dY16 == nullptr ||
+          (reinterpret_cast<uintptr_t>(p.S) & 15) || (reinterpret_cast<uintptr_t>(p.dY16) & 15) ||
+          (((long long)p.cs * 2) & 15) || ((p.ns * 2) & 15) || p.nl * 2 * p.th * nq8 > 160)
+        return -4;
+      if (p.nl == 2) {
+        if (p.dY16_2 == nullptr || p.partial2 == nullptr || p.pa2 == nullptr || p.pb2 == nullptr || p.Cin2 < 16 ||
+            p.Cin2 > p.Cin || (p.Cin & 15) || (p.Cin2 & 15) || (reinterpret_cast<uintptr_t>(p.dY16_2) & 15))
+          return -4;
+        return d3_wgrad_launch_t<1, D3_BF16, ST_BF16, ST_BF16, 2, true>(p, s);
+      }
+      return d3_wgrad_launch_t<1, D3_BF16, ST_BF16, ST_BF16, 1, true>(p, s);
+    }
+    if (p.nl == 2) return -4;
     return d3_wgrad_launch_t<1, D3_BF16, ST_BF16>(p, s);
   }
   if (p.yt == ST_BF16) {  // fp32 stacks + the bf16 copy of dY (one bf16 part; 8-pixel dY units)

@@ -2099,8 +2099,14 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
         return fail(RLN_ERR_UNSUPPORTED, "dense weight gradient not covered by the bf16-storage kernel");
       if (d3_wgrad_supported(g)) {  // transposed-read 16-bit MFMA kernel
         d3_wgrad_plan(lv.H, lv.W, N, o.cin, &g);
+        static const bool no_z8 = rln_env("RLN_NO_WG_Z8") != nullptr;
         if (use_dy16 && (g.tw % 8) == 0) {
           g.dY16 = dy16_j;
+          g.yt = ST_BF16;
+        } else if (!no_z8 && lv.st == ST_BF16 && (g.tw % 8) == 0 && (lv.W % 8) == 0 && o.cout <= 16 &&
+                   wgrad_parts(c, (long long)N * lv.H * lv.W) == 1 && c->d3_bwd_dt == D3_BF16) {
+          g.z8 = 1;  // bf16 stacks: 8-pixel units; the bf16 dY buffer itself is the operand
+          g.dY16 = dYj;
           g.yt = ST_BF16;
         }
 #ifdef RLN_DIAG
@@ -2120,13 +2126,14 @@ int bwd_dense_block(rln_ctx* c, int k0, int k1, hipStream_t s) {
           g2.pa = c->ab + ob.bn.ab;
           g2.pb = c->ab + c->n_ab + ob.bn.ab;
           g2.dY = c->dyblk[(size_t)j + 1];
-          g2.dY16 = static_cast<unsigned char*>(c->dy16) + (size_t)((j + 1) & 1) * c->dy16_half;
+          g2.dY16 = g.z8 ? static_cast<void*>(c->dyblk[(size_t)j + 1])
+                         : static_cast<void*>(static_cast<unsigned char*>(c->dy16) + (size_t)((j + 1) & 1) * c->dy16_half);
           g2.partial = c->wpartial;
           g2.nl = 2;
           g2.Cin2 = o.cin;
           g2.pa2 = g.pa;
           g2.pb2 = g.pb;
-          g2.dY16_2 = dy16_j;
+          g2.dY16_2 = g.dY16;
           g2.partial2 = c->wpartial2;
           {
             const double wflops = 2.0 * o.cout * ((double)o.cin + ob.cin) * 9.0 * plane * N;
