@@ -1662,7 +1662,8 @@ int d3_pull_finalize(const D3PullFin& f, hipStream_t s) {
 // compiler keeps an s_cbranch_execz around each, so the wait-count pass drains every outstanding memory operation
 // there; straight-line tails for whole-tile / all-or-nothing-accumulate launches (two more template variants) plus the
 // first fragment load hoisted out of the item loop brought the stamped tail to 11 % but the step from 24.48 to 24.62 ms
-// (A/B on one box, tools/ab_bench.sh): not kept.)
+// (A/B on one box, tools/ab_bench.sh): not kept.  Nor is an M-tile-major step order whose per-M-tile epilogue slices are
+// issued between the next M-tile's MFMAs (no extra registers, bit-identical): +0.16 ms per step.)
 int d3_pull_nsub(const D3Pull& p) { return p.C <= 16 ? 5 : 2; }
 
 static size_t d3_pull_lds(const D3Pull& p, int np) {
