@@ -57,7 +57,19 @@ struct D3Fwd {
   long long split_stride;
   int dbg;              // diagnostic builds (-DRLN_DIAG) only: 1 no global loads, 2 no commit, 4 no MFMA phase, 8 no zero-init
   int st;               // storage element type of S and out (storage.h): ST_F32, or ST_BF16 (then np = 1, bf16 operands)
+  // finishing launch of a pair (d3_fwd_launch): only the chunks from c_first on are multiplied; the raw sums of the
+  // earlier chunks (fp32 [N][Cout][H][W], written by the paired launch of the previous layer) are added in the epilogue
+  int c_first;
+  const float* partial_in;
+  // paired launch (d3_fwd_pair_launch): this layer (all Cin chunks; Cin % 16 == 0) and the NEXT layer of the block over the
+  // same chunks: the next layer's BN table, forward fragments and raw-sum destination
+  const float* pa2;
+  const float* pb2;
+  const uint4* wpk2;
+  float* partial_out;
 };
+// both layers of a block over the channels they share, one load per chunk (see d3_fwd2_k); same tile plan as d3_fwd_launch
+int d3_fwd_pair_launch(const D3Fwd& p, int N, int np, int dt, hipStream_t s);
 // true when the launch geometry is supported (W % 4 == 0, 16-byte aligned planes, W >= 40, Cout <= 16)
 bool d3_fwd_supported(const D3Fwd& p);
 void d3_fwd_pick_tile(int H, int W, int np, int* th, int* tw, int* rg, int st = 0);

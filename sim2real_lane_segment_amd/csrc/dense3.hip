@@ -132,8 +132,12 @@ __global__ __launch_bounds__(768, 3) void d3_fwd_k(const D3Fwd p) {
   const SP<ST> Sn = SP<ST>(p.S) + (long long)n * p.ns;
 
   // chunk range of this block (split-K over blockIdx.y)
-  const int per = (nchunk_all + (int)gridDim.y - 1) / (int)gridDim.y;
-  const int c_begin = (int)blockIdx.y * per;
+  // (c_first > 0: the launch only adds the chunks from c_first on to the raw sums p.partial_in of the earlier chunks,
+  // which a paired launch of the previous layer accumulated -- see d3_fwd2_k)
+  constexpr bool FIN = (NP == 1);  // pairs exist for one-part operands only: the other variants keep their code
+  const int c_first = FIN ? p.c_first : 0;
+  const int per = (nchunk_all - c_first + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int c_begin = c_first + (int)blockIdx.y * per;
   const int c_end = min(nchunk_all, c_begin + per);
 
   // ---- one-time LDS setup: zero the padding cells (image cells outside the picture; everything else is rewritten by
@@ -393,9 +397,14 @@ __global__ __launch_bounds__(768, 3) void d3_fwd_k(const D3Fwd p) {
       const int gy = gy0 + ty, gx = gx0 + tx;
       const bool ok = jv && (q < npix) && (gy < p.H) && (gx < p.W);
       float v[4];
+      float4 pin = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (FIN && p.partial_in != nullptr && ok)
+        pin = *reinterpret_cast<const float4*>(p.partial_in + ((long long)n * p.Cout + j) * ((long long)p.H * p.W) +
+                                               (long long)gy * p.W + gx);
+      const float pv[4] = {pin.x, pin.y, pin.z, pin.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        v[r] = st_round<ST>(fmaf(acc[m][r], w_unscale<DT>(), bias) * sc);  // statistics of the tensor as it is stored
+        v[r] = st_round<ST>(fmaf(acc[m][r] + pv[r], w_unscale<DT>(), bias) * sc);  // statistics of the tensor as it is stored
         if (ok) {
           s1 += v[r];
           s2 += v[r] * v[r];
@@ -405,6 +414,324 @@ __global__ __launch_bounds__(768, 3) void d3_fwd_k(const D3Fwd p) {
     }
   }
   if (p.stat_partial != nullptr && !raw) {
+    if (!producer) {
+      s1 = group4_sum(s1);
+      s2 = group4_sum(s2);
+      if ((lane >> 4) == 0) {
+        red[(wave * 16 + (lane & 15)) * 2 + 0] = s1;
+        red[(wave * 16 + (lane & 15)) * 2 + 1] = s2;
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * p.Cout) {
+      const int jj = tid >> 1, w2 = tid & 1;
+      const float t = red[(0 * 16 + jj) * 2 + w2] + red[(1 * 16 + jj) * 2 + w2] + red[(2 * 16 + jj) * 2 + w2] +
+                      red[(3 * 16 + jj) * 2 + w2];
+      const long long brow = (long long)n * gridDim.x + bx;
+      p.stat_partial[(brow * p.Cout + jj) * 2 + w2] = t;
+    }
+  }
+}
+
+// =============================================================================================
+// forward of TWO consecutive layers of a block over the input channels they share (layer-alternating pipeline)
+//
+// Layer j+1 consumes every input channel of layer j (plus layer j's 16 outputs), each through its own BatchNorm.  The
+// two LDS images of d3_fwd_k's double buffer become "layer j's image" and "layer j+1's image" of the SAME 16-channel
+// chunk: a chunk is LOADED once, converted twice (iteration 2c-1: image 0 with layer j's table, iteration 2c: image 1
+// with layer j+1's), and the consumers alternate between the two images and two accumulator sets.  The loads halve per
+// layer, a register set stays in flight for three iterations, and the conversion of one image still overlaps the MFMAs
+// on the other.  Layer j leaves through the normal epilogue; layer j+1's raw sums over the shared chunks go to
+// p.partial_out, and a d3_fwd_k launch restricted to its last chunk (c_first, partial_in) completes it once layer j's
+// output and statistics exist (the new channels' BatchNorm needs batch statistics: a grid-wide dependency).
+// Measured (bf16 stacks, 120x160, batch 64): 317 us for the pair against 2 x 216 us, but the one-chunk finishing launch
+// costs 73 us (fp32 raw sums out and back in), so a pair nets ~40 us: 18.29 -> 18.09 ms per step.  Conversion and LDS
+// reads are per layer and do not shrink; only the global loads are shared.  One-part operands only (see the launcher).
+// =============================================================================================
+template <int MPW, int NP, int DT, int ST>
+__global__ __launch_bounds__(768, 3) void d3_fwd2_k(const D3Fwd p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool producer = wave >= 4;
+  const int P = p.tw + 3;  // odd pixel pitch
+  const int rows = p.th + 2;
+  const int PLANE = rows * P * 32;
+  const int IMG = NP * PLANE + 5 * NP * 1024;  // one image: parts + weight fragments of the (layer, chunk) item
+  const int nck = p.Cin >> 4;                  // shared chunks (Cin of the first layer: a multiple of 16)
+  const int Cpad = nck * 16;
+  float* abtab = reinterpret_cast<float*>(smem + 2 * IMG);  // [2 layers][a[Cpad], b[Cpad]]
+  float* red = abtab + 4 * Cpad;
+
+  int bx = blockIdx.x, n = blockIdx.z;
+  {
+    const unsigned lin = blockIdx.x + gridDim.x * blockIdx.z;
+    const unsigned lg = xcd_logical_block(lin, gridDim.x * gridDim.z);
+    n = (int)(lg / gridDim.x);
+    bx = (int)(lg - (unsigned)n * gridDim.x);
+  }
+  const int tile_y = bx / p.tiles_x, tile_x = bx - tile_y * p.tiles_x;
+  const int gy0 = tile_y * p.th, gx0 = tile_x * p.tw;
+  const SP<ST> Sn = SP<ST>(p.S) + (long long)n * p.ns;
+  const int I = 2 * nck;  // items: (chunk t >> 1, layer t & 1); item t lives in image t & 1
+
+  auto lds_setup = [&]() __attribute__((always_inline)) {
+    const int cells = rows * P;
+    for (int i = tid; i < cells; i += 768) {
+      const int r = i / P, cpos = i - r * P;
+      const int iy = gy0 - 1 + r, ix = gx0 - 1 + cpos;
+      if (iy < 0 || iy >= p.H || ix < 0 || ix >= p.W || cpos > p.tw + 1) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int pt = 0; pt < NP; ++pt) {
+            uint4* z = reinterpret_cast<uint4*>(smem + b * IMG + pt * PLANE + i * 32);
+            z[0] = make_uint4(0u, 0u, 0u, 0u);
+            z[1] = make_uint4(0u, 0u, 0u, 0u);
+          }
+      }
+    }
+    for (int i = tid; i < Cpad; i += 768) {
+      abtab[i] = p.pa[i];
+      abtab[Cpad + i] = p.pb[i];
+      abtab[2 * Cpad + i] = p.pa2[i];
+      abtab[3 * Cpad + i] = p.pb2[i];
+    }
+  };
+
+  const int npix = p.th * p.tw;
+  float s1 = 0.f, s2 = 0.f;  // (the accumulators live in the consumer branch only: the producers' registers hold two chunks)
+
+  if (producer) {
+    const int ptid = tid - 256;
+    constexpr int PXU = 4;
+    const int nq = p.tw / PXU;
+    const int rgs = p.rg == 2 ? 1 : 2;
+    const int qpg = 4 >> rgs;
+    const int nqg = (nq + qpg - 1) / qpg;
+    const int nrg = (rows + p.rg - 1) >> rgs;
+    int s_off[8], s_lds, s_o;
+    bool s_ok;
+    {
+      const int lu = ptid;
+      const int o = lu & 1, rr = (lu >> 1) & (p.rg - 1), qq = (lu >> (1 + rgs)) & (qpg - 1), u = lu >> 3;
+      const int R = u / nqg, Q = (u - R * nqg) * qpg + qq;
+      const int r = (R << rgs) + rr;
+      const int iy = gy0 - 1 + r, ix = gx0 + PXU * Q;
+      const bool ok = (R < nrg) && (r < rows) && (Q < nq) && (iy >= 0) && (iy < p.H) && (ix < p.W);
+      s_ok = ok;
+      const int goff = ok ? iy * p.W + ix : 0;
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) s_off[cc] = (o * 8 + cc) * p.cs + goff;
+      s_lds = ((ok ? r : 0) * P + 1 + PXU * (ok ? Q : 0)) * 32 + o * 16;
+      s_o = o;
+    }
+    const int h_cp = ptid & 7, h_side = (ptid >> 3) & 1, h_r = ptid >> 4;
+    const int h_iy = gy0 - 1 + h_r, h_ix = h_side ? gx0 + p.tw : gx0 - 1;
+    const bool h_ok = (h_r < rows) && (h_iy >= 0) && (h_iy < p.H) && (h_ix >= 0) && (h_ix < p.W);
+    const int h_goff = (h_ok ? h_iy * p.W + h_ix : 0) + 2 * h_cp * p.cs;
+    const int h_lds = ((h_ok ? h_r : 0) * P + (h_side ? p.tw + 1 : 0)) * 32 + h_cp * 4;
+    constexpr int NBE = 5 * NP * 64;
+    constexpr int NB = (NBE + 511) / 512;
+    struct Stage {
+      typename SRaw<ST>::r4 s[8];
+      typename SRaw<ST>::r1 h[2];
+      uint4 b[NB];  // weight fragments of the chunk: layer 0's from issue(), replaced by layer 1's when layer 0's are committed
+    };
+    auto issue = [&](int chunk, Stage& R) __attribute__((always_inline)) {
+      const SP<ST> base = Sn + (long long)chunk * 16 * p.cs;  // wave-uniform
+      const uint4* wp0 = p.wpk + (long long)chunk * NBE;
+#pragma unroll
+      for (int i = 0; i < NB; ++i) R.b[i] = wp0[min(ptid + 512 * i, NBE - 1)];
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) R.s[cc] = base.raw4(s_off[cc]);
+      R.h[0] = base.raw1(h_goff);
+      R.h[1] = base.raw1(h_goff + p.cs);
+    };
+    // item (chunk, L): the chunk's raw values through layer L's table into image L
+    auto commit = [&](int chunk, int L, Stage& R) __attribute__((always_inline)) {
+      const int cb = chunk * 16;
+      // the image base is re-materialised as an opaque value at every call: as loop invariants the LDS addresses of the
+      // four commit sites of the steady-state loop cost ~40 VGPRs (spills at the 168-register budget of 12 waves)
+      int ibase = L * IMG;
+      asm volatile("" : "+v"(ibase));
+      unsigned char* buf = smem + ibase;
+      const float* tab = abtab + L * 2 * Cpad;
+      uint4* btile = reinterpret_cast<uint4*>(buf + NP * PLANE);
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+        if (ptid + 512 * i < NBE) btile[ptid + 512 * i] = R.b[i];
+      if (L == 0) {  // the same chunk's fragments of the second layer: one iteration ahead of their commit
+        const uint4* wp1 = p.wpk2 + (long long)chunk * NBE;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) R.b[i] = wp1[min(ptid + 512 * i, NBE - 1)];
+      }
+      if (h_ok) {
+        const int c0 = cb + 2 * h_cp;
+        unsigned parts[NP];
+        split2<DT, NP>(relu16<DT>(fmaf(tab[c0], SRaw<ST>::w1(R.h[0]), tab[Cpad + c0])),
+                       relu16<DT>(fmaf(tab[c0 + 1], SRaw<ST>::w1(R.h[1]), tab[Cpad + c0 + 1])), parts);
+#pragma unroll
+        for (int pt = 0; pt < NP; ++pt) *reinterpret_cast<unsigned*>(buf + pt * PLANE + h_lds) = parts[pt];
+      }
+      if (s_ok) {
+        const float* ab = tab + cb + s_o * 8;
+        const float4 a0 = *reinterpret_cast<const float4*>(ab), a1 = *reinterpret_cast<const float4*>(ab + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(ab + Cpad);
+        const float4 b1 = *reinterpret_cast<const float4*>(ab + Cpad + 4);
+        const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int px = 0; px < PXU; ++px) {
+          unsigned parts[4][NP];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float4 u0 = SRaw<ST>::w4(R.s[2 * k]), u1 = SRaw<ST>::w4(R.s[2 * k + 1]);
+            const float x0 = px == 0 ? u0.x : px == 1 ? u0.y : px == 2 ? u0.z : u0.w;
+            const float x1 = px == 0 ? u1.x : px == 1 ? u1.y : px == 2 ? u1.z : u1.w;
+            split2<DT, NP>(relu16<DT>(fmaf(av[2 * k], x0, bv[2 * k])),
+                           relu16<DT>(fmaf(av[2 * k + 1], x1, bv[2 * k + 1])), parts[k]);
+          }
+#pragma unroll
+          for (int pt = 0; pt < NP; ++pt)
+            *reinterpret_cast<uint4*>(buf + pt * PLANE + s_lds + px * 32) =
+                make_uint4(parts[0][pt], parts[1][pt], parts[2][pt], parts[3][pt]);
+        }
+      }
+    };
+    // Chunk c lives in register set c & 1.  Iteration t (consumers multiply item t) commits item t + 1:
+    //   t = 2c     : (c, layer 1) from set(c); the set is free afterwards -> refill it with chunk c + 2
+    //   t = 2c + 1 : (c + 1, layer 0) from set(c + 1)
+    Stage RA, RB;
+    if (nck > 0) issue(0, RA);
+    if (nck > 1) issue(1, RB);
+    lds_setup();
+    __syncthreads();
+    if (nck > 0) commit(0, 0, RA);
+    __syncthreads();  // start of iteration 0
+    int c = 0;
+    for (; c + 3 < nck; c += 2) {  // steady state: four iterations per trip, no branches around the loads
+      commit(c, 1, RA);
+      issue(c + 2, RA);
+      __syncthreads();
+      commit(c + 1, 0, RB);
+      __syncthreads();
+      commit(c + 1, 1, RB);
+      issue(c + 3, RB);
+      __syncthreads();
+      commit(c + 2, 0, RA);
+      __syncthreads();
+    }
+    for (; c < nck; ++c) {  // tail: iterations 2c and 2c + 1
+      if (c & 1) commit(c, 1, RB); else commit(c, 1, RA);
+      if (c + 2 < nck) {
+        if (c & 1) issue(c + 2, RB); else issue(c + 2, RA);
+      }
+      __syncthreads();
+      if (c + 1 < nck) {
+        if ((c + 1) & 1) commit(c + 1, 0, RB); else commit(c + 1, 0, RA);
+      }
+      __syncthreads();
+    }
+  } else {
+    const int lp = lane & 15, lg = lane >> 4;
+    int basem[MPW];
+#pragma unroll
+    for (int m = 0; m < MPW; ++m) {
+      const int q = min((wave * MPW + m) * 16 + lp, npix - 1);
+      const int ty = q / p.tw, tx = q - ty * p.tw;
+      basem[m] = ((ty + 1) * P + tx + 1) * 32 + (lg & 1) * 16;
+    }
+    int toff[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      const int tap = min(2 * s + (lg >> 1), 8);
+      toff[s] = ((tap / 3 - 1) * P + (tap % 3 - 1)) * 32;
+    }
+    f32x4 acc[2][MPW];
+#pragma unroll
+    for (int L = 0; L < 2; ++L)
+#pragma unroll
+      for (int m = 0; m < MPW; ++m) acc[L][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    lds_setup();
+    __syncthreads();
+    __syncthreads();  // first item staged
+    auto mma_item = [&](int ioff, f32x4 (&a)[MPW]) __attribute__((always_inline)) {
+      // per-item opaque bases: hoisted out of the chunk loop, the 2 x 50 x NP fragment addresses of the two images are
+      // loop invariants the register allocator spills (a scratch reload in front of every MFMA)
+      asm volatile("" : "+v"(ioff));
+      const unsigned char* img = smem + ioff;
+      int bm[MPW];
+#pragma unroll
+      for (int m = 0; m < MPW; ++m) {
+        bm[m] = basem[m];
+        asm volatile("" : "+v"(bm[m]));
+      }
+      const uint4* btile = reinterpret_cast<const uint4*>(img + NP * PLANE);
+      constexpr int DEPTH = 3, RING = DEPTH + 1, STEPS = 5 * MPW;
+      uint4 af[RING][NP], bf[2][NP];
+#pragma unroll
+      for (int pt = 0; pt < NP; ++pt) bf[0][pt] = btile[pt * 64 + lane];
+#pragma unroll
+      for (int i = 0; i < DEPTH && i < STEPS; ++i) {
+        const int s0 = i / MPW, m0 = i - s0 * MPW;
+#pragma unroll
+        for (int pt = 0; pt < NP; ++pt)
+          af[i % RING][pt] = *reinterpret_cast<const uint4*>(img + pt * PLANE + bm[m0] + toff[s0]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < STEPS; ++i) {
+        const int s = i / MPW, m = i - s * MPW;
+        if (i + DEPTH < STEPS) {
+          const int s1 = (i + DEPTH) / MPW, m1 = (i + DEPTH) - s1 * MPW;
+#pragma unroll
+          for (int pt = 0; pt < NP; ++pt)
+            af[(i + DEPTH) % RING][pt] = *reinterpret_cast<const uint4*>(img + pt * PLANE + bm[m1] + toff[s1]);
+        }
+        if (m == 0 && s + 1 < 5) {
+#pragma unroll
+          for (int pt = 0; pt < NP; ++pt) bf[(s + 1) & 1][pt] = btile[((s + 1) * NP + pt) * 64 + lane];
+        }
+        a[m] = mfma_split<DT, NP>(af[i % RING], bf[s & 1], a[m]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    for (int c = 0; c < nck; ++c) {
+      mma_item(0, acc[0]);
+      __syncthreads();
+      mma_item(IMG, acc[1]);
+      __syncthreads();
+    }
+    // ---- epilogue: layer 0 like d3_fwd_k; layer 1: raw sums over the shared chunks ----
+    const int j = lp;
+    const bool jv = j < p.Cout;
+    const float bias = (jv && p.bias) ? p.bias[j] : 0.f;
+    const float sc = (jv && p.nscale) ? p.nscale[(long long)n * p.Cout + j] : 1.f;
+    const SP<ST> outn = SP<ST>(p.out) + ((long long)n * p.out_ns + (long long)(jv ? j : 0) * p.out_cs);
+    float* pout = p.partial_out + ((long long)n * p.Cout + (jv ? j : 0)) * ((long long)p.H * p.W);
+#pragma unroll
+    for (int m = 0; m < MPW; ++m) {
+      const int q = (wave * MPW + m) * 16 + lg * 4;
+      const int ty = q / p.tw, tx = q - ty * p.tw;
+      const int gy = gy0 + ty, gx = gx0 + tx;
+      const bool ok = jv && (q < npix) && (gy < p.H) && (gx < p.W);
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = st_round<ST>(fmaf(acc[0][m][r], w_unscale<DT>(), bias) * sc);
+        if (ok) {
+          s1 += v[r];
+          s2 += v[r] * v[r];
+        }
+      }
+      if (ok) {
+        outn.st4((long long)gy * p.W + gx, v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(pout + (long long)gy * p.W + gx) =
+            make_float4(acc[1][m][0], acc[1][m][1], acc[1][m][2], acc[1][m][3]);
+      }
+    }
+  }
+  if (p.stat_partial != nullptr) {
     if (!producer) {
       s1 = group4_sum(s1);
       s2 = group4_sum(s2);
@@ -482,6 +809,7 @@ static int d3_fwd_launch_t(const D3Fwd& p, int N, hipStream_t s) {
 
 int d3_fwd_launch(const D3Fwd& p, int N, int np, int dt, hipStream_t s) {
   if (!d3_fwd_supported(p)) return -4;
+  if ((p.c_first != 0 || p.partial_in != nullptr) && np != 1) return -4;  // finishing launches: one-part operands only
   // tile capacity: 64*MPW pixels; staging rounds NR = ceil(8 * ceil((th+2)/4) * (tw/4) / 256)
   const int npix = p.th * p.tw;
   const int qpg = 4 / p.rg;
@@ -508,6 +836,55 @@ int d3_fwd_launch(const D3Fwd& p, int N, int np, int dt, hipStream_t s) {
   if (npix <= 320) D3_FWD(5, 1);
   if (npix <= 640) D3_FWD(10, 1);
 #undef D3_FWD
+  return -4;
+}
+
+template <int MPW, int NP, int DT, int ST = ST_F32>
+static int d3_fwd_pair_launch_t(const D3Fwd& p, int N, hipStream_t s) {
+  const int P = p.tw + 3, rows = p.th + 2;
+  const size_t lds = 2 * ((size_t)NP * rows * P * 32 + (size_t)5 * NP * 1024) + (size_t)4 * p.Cin * 4 + 4 * 16 * 2 * 4;
+  auto kern = d3_fwd2_k<MPW, NP, DT, ST>;
+  static DevOnce attr_once;
+  if (attr_once.first()) {
+    const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    if (attr_err != hipSuccess) {
+      (void)hipGetLastError();
+      attr_once.undo();
+      return (int)attr_err;
+    }
+  }
+  if (lds > 160 * 1024) return -4;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_x * p.tiles_y), 1, (unsigned)N), dim3(768), lds, s, p);
+  return (int)hipGetLastError();
+}
+
+// One-part operands only: with two parts the producer's second register set does not fit the 168-VGPR budget of a
+// 12-wave block (216 bytes of scratch; measured 663 us against 2 x 300 us for the two single launches at 120x160).
+int d3_fwd_pair_launch(const D3Fwd& p, int N, int np, int dt, hipStream_t s) {
+  if (np != 1) return -4;
+  if (!d3_fwd_supported(p) || p.ksplit > 1 || (p.Cin & 15) || p.Cin < 16 || p.c_first != 0) return -4;
+  if (!p.pa2 || !p.pb2 || !p.wpk2 || !p.partial_out || (reinterpret_cast<uintptr_t>(p.partial_out) & 15)) return -4;
+  const int npix = p.th * p.tw;
+  const int qpg = 4 / p.rg;
+  const int lane_units = 8 * ((p.th + 2 + p.rg - 1) / p.rg) * ((p.tw / 4 + qpg - 1) / qpg);
+  if ((p.th + 2) * 16 > 512 || lane_units > 512 || (p.tw % 4) || (p.rg != 2 && p.rg != 4)) return -4;
+#define D3_FWD2(MPW_)                                                                            \
+  do {                                                                                           \
+    if (p.st == ST_BF16) {                                                                       \
+      if (np != 1 || dt != D3_BF16) return -4;                                                   \
+      return d3_fwd_pair_launch_t<MPW_, 1, D3_BF16, ST_BF16>(p, N, s);                           \
+    }                                                                                            \
+    if (dt == D3_BF16) {                                                                         \
+      if (np == 1) return d3_fwd_pair_launch_t<MPW_, 1, D3_BF16>(p, N, s);                       \
+      return -4;                                                                                 \
+    }                                                                                            \
+    if (np == 1) return d3_fwd_pair_launch_t<MPW_, 1, D3_F16>(p, N, s);                          \
+    return -4;                                                                                   \
+  } while (0)
+  if (npix <= 320) D3_FWD2(5);
+  if (npix <= 640) D3_FWD2(10);
+#undef D3_FWD2
   return -4;
 }
 

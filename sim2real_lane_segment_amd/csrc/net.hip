@@ -167,6 +167,8 @@ struct rln_ctx {
   void* dy16 = nullptr;  // bf16 copies of dense layers' finalised output gradients (the weight gradient's one-part operand):
   size_t dy16_half = 0;  // two buffers of this many bytes, by layer parity (two-layer weight-gradient launches)
   float* wpartial2 = nullptr;  // slabs of the secondary layer of a two-layer launch
+  float* fpair = nullptr;      // raw sums of the second layer of a paired dense forward (dense3.h: D3Fwd.partial_out)
+  long long pair_finish = -1;  // op whose forward completes a paired launch (c_first / partial_in), or -1
   int dy_flip = 0;
   bool use_side = false;
   // forward/backward hand-over state
@@ -780,6 +782,9 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
   int* lcounts = cv.take<int>(32 + 256);
   float* lpartial = cv.take<float>((size_t)loss_blocks((long long)n * hw0) * 4);
   float* lresult = cv.take<float>(64);
+  // second layer's raw sums of a paired dense forward (one-part operands only; last, so that every other buffer keeps
+  // its offset whether or not the mode uses it)
+  float* fpair = c->d3_fwd_np == 1 ? cv.take<float>((size_t)n * 16 * h * w) : nullptr;
   if (assign) {
     for (int L = 0; L <= nd; ++L) {
       c->levels[L].H = hs[L];
@@ -800,6 +805,7 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
     c->pool_idx = pool_idx;
     c->pool_off = pool_off;
     c->fsplit = fsplit;
+    c->fpair = fpair;
     c->dY = dY;
     c->dYbuf[0] = dY;
     c->dYbuf[1] = dY2;
@@ -1040,7 +1046,61 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
       q.tiles_y = (q.H + q.th - 1) / q.th;
       q.tiles_x = (q.W + q.tw - 1) / q.tw;
       int e3;
-      {
+      // Paired forward (dense3.h: d3_fwd_pair_launch): this layer and the next one of the block over the input channels
+      // they share, one load per chunk; the next op then only adds its last chunk (c_first / partial_in).
+      static const bool no_fwd_pair = rln_env("RLN_NO_FWD_PAIR") != nullptr;
+      bool paired = false;
+      if (c->pair_finish == (long long)k) {  // second layer of a pair: the chunks before c_first are in fpair already
+        const Op& prev = c->ops[k - 1];
+        q.c_first = prev.cin / 16;
+        q.partial_in = c->fpair;
+        c->pair_finish = -1;
+      } else if (!no_fwd_pair && c->d3_fwd_np == 1 && sp3 == 1 && c->fpair != nullptr && o.cout == 16 && (o.cin % 16) == 0) {
+        auto chained = [&](size_t a) {  // op a+1 is the next layer of the same block
+          if (a + 1 >= c->ops.size()) return false;
+          const Op& x0 = c->ops[a];
+          const Op& x1 = c->ops[a + 1];
+          return x1.type == OP_DENSE && x0.type == OP_DENSE && x1.dst_level == x0.dst_level && x1.in_off == x0.in_off &&
+                 x1.cin == x0.cin + x0.cout && x1.cout == 16 && x0.cout == 16 && c->d3_wf_off[a + 1] >= 0 &&
+                 x1.out_off == x0.out_off + x0.cout;
+        };
+        int run = 1;  // consecutive chained dense layers from k on: pair (k, k+1) when that number is even
+        while (chained(k + run - 1)) ++run;
+        if (run >= 2 && (run % 2) == 0) {
+          const Op& nx = c->ops[k + 1];
+          // the next layer's BN table over the channels both layers read (their statistics exist; no running-stat update here:
+          // the statistics pass of this layer prepares the complete table, running statistics included)
+          {
+            const Level& lvn = c->levels[nx.src_level];
+            const int64_t son = lvn.stat_off + nx.in_off;
+            const double count = (double)c->N * lvn.H * lvn.W;
+            ProfScope psb(c, PC_BN, 0, 0, s);
+            if (!(!training && c->eval_reuse))
+              RLN_TRY(bn_prep(training, o.cin, c->params + nx.bn.gamma, c->params + nx.bn.beta, c->mean + son, c->var + son,
+                              c->invstd + son, training ? nullptr : c->bnrun + nx.bn.rmean,
+                              training ? nullptr : c->bnrun + nx.bn.rvar, c->cfg.bn_momentum, count, c->cfg.bn_eps,
+                              c->ab + nx.bn.ab, c->ab + c->n_ab + nx.bn.ab, s));
+          }
+          D3Fwd q2 = q;
+          q2.pa2 = c->ab + nx.bn.ab;
+          q2.pb2 = c->ab + c->n_ab + nx.bn.ab;
+          q2.wpk2 = c->d3_packed + c->d3_wf_off[k + 1];
+          q2.partial_out = c->fpair;
+          const double flops = 2.0 * 2.0 * o.cin * o.cout * 9.0 * q.H * q.W * N;
+          const double bytes = (double)N * q.H * q.W * (st_bytes(dl.st) * ((double)o.cin + o.cout) + 4.0 * o.cout);
+          ProfScope ps(c, q.th * q.tw > 320 ? PC_D3_FWD : PC_D3_FWD_S, flops, bytes, s);
+          const int e2 = d3_fwd_pair_launch(q2, N, c->d3_fwd_np, c->d3_fwd_dt, s);
+          if (e2 == 0) {
+            paired = true;
+            c->pair_finish = (long long)k + 1;
+          } else if (e2 != RLN_ERR_UNSUPPORTED) {
+            return fail(e2, "d3_fwd_pair_launch failed with %d (op %zu)", e2, k);
+          }
+        }
+      }
+      if (paired) {
+        e3 = 0;
+      } else {
         const double flops = 2.0 * o.cin * o.cout * 9.0 * q.H * q.W * N;
         const double bytes = (double)st_bytes(dl.st) * N * ((double)o.cin + o.cout) * q.H * q.W;
         // one class per kernel instantiation, so that a class's average launch time is a row of the rocprofv3 summary:
@@ -1048,6 +1108,7 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
         ProfScope ps(c, q.th * q.tw > 320 ? PC_D3_FWD : PC_D3_FWD_S, flops, bytes, s);
         e3 = d3_fwd_launch(q, N, c->d3_fwd_np, c->d3_fwd_dt, s);
       }
+      if (e3 != 0 && q.partial_in != nullptr) return fail(e3, "the finishing launch of a paired forward failed (op %zu)", k);
       // RLN_ERR_UNSUPPORTED from the launcher (tile / LDS budget of an unusual geometry) falls through to the exact-fp32
       // family below, like a geometry d3_fwd_supported() rejects; nothing was launched in that case
       if (e3 != 0 && (e3 != RLN_ERR_UNSUPPORTED || dl.st != ST_F32))
@@ -2540,6 +2601,7 @@ int rln_forward(rln_ctx* c, const float* x, int n, int h, int w, int training, c
     if (c->nbt) RLN_TRY(add_one_i64((long long*)c->nbt, c->n_nbt, s));
   }
   c->prep_done = -1;
+  c->pair_finish = -1;
   // frozen-model loops (rln_set_eval_cache): the forward weight fragments and the folded BatchNorm tables of the
   // previous eval forward are still those of the arena
   c->eval_reuse = (!training && c->eval_cache_on && c->eval_tables_valid) ? 1 : 0;

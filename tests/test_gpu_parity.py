@@ -538,6 +538,25 @@ def test_named_variants_train_step_vs_oracle(variant):
     # floor says (FCDenseNet103 at 64x96 has 21 tensors whose floor alone is above 1e-2: 2x3-pixel maps at the bottom of a
     # 100-layer net).  Measured on MI355X: FCDenseNet57 median 7.7e-4 / max 7.5e-3 / arena 1.9e-4, FCDenseNet103
     # median 9.4e-4 / max 4.9e-3 / arena 4.8e-4 -- the ill-conditioned tensors sit at 1.7e-3, well inside their floor.
+    #
+    # FCDenseNet103's gradients at this size are not continuous in the input at fp32 resolution: the oracle's OWN gradients
+    # move by up to 2.7e-2 per tensor (arena 2e-3) when x is scaled by (1 + 1e-7) -- a discrete event (ReLU / max-pool
+    # selection at the 2x3..8x12 levels) that any change of summation order can toggle as well (tools/pair_diff.py: a
+    # build that only reorders the fp32 sums of the dense forward lands on the oracle's other branch, probabilities equal
+    # to 3e-7).  So for that variant the oracle is run a second time on the scaled input and a tensor may differ by twice
+    # the oracle's own sensitivity where that exceeds the fixed bound; FCDenseNet57 keeps the fixed bounds.
+    sens, arena_sens = {}, 0.0
+    if variant == "103":
+        ts2 = O.TrainState({k: v.clone() for k, v in st.items()})
+        _, _, grads2, _ = O.train_step(ts2, x * (1.0 + 1e-7), y, cfg, scales, apply_update=False)
+        n2 = d2 = 0.0
+        for k, g in grads.items():
+            floor = 1e-5 * g.numel() ** 0.5
+            sens[k] = float((grads2[k] - g).norm()) / max(float(g.norm()), floor)
+            n2 += float((grads2[k] - g).double().pow(2).sum())
+            d2 += float(g.double().pow(2).sum())
+        arena_sens = float(np.sqrt(n2 / d2))
+        print(f"[fcd103] oracle sensitivity to x*(1+1e-7): max {max(sens.values()):.2e}, arena {arena_sens:.2e}")
     table = f"fcd{variant}_2x64x96"
     bad, errs = [], []
     num = den = 0.0
@@ -548,13 +567,13 @@ def test_named_variants_train_step_vs_oracle(variant):
         errs.append(l2)
         num += float((got - g).double().pow(2).sum())
         den += float(g.double().pow(2).sum())
-        if not l2 < 1e-2:
-            bad.append((k, l2, _noise_floor(table, k)))
+        if not l2 < max(1e-2, 2.0 * sens.get(k, 0.0)):
+            bad.append((k, l2, sens.get(k, 0.0), _noise_floor(table, k)))
     errs = np.array(errs)
     print(f"[fcd{variant}] gradient L2-relative error vs the oracle: median {np.median(errs):.2e}, p90 "
           f"{np.quantile(errs, 0.9):.2e}, max {errs.max():.2e}, arena {np.sqrt(num / den):.2e}")
     assert not bad, f"{len(bad)} gradient tensors off: {bad[:10]}"
-    assert np.sqrt(num / den) < 1e-3 and float(np.median(errs)) < 2e-3
+    assert np.sqrt(num / den) < max(1e-3, 2.0 * arena_sens) and float(np.median(errs)) < 2e-3
 
 
 def test_differentiable_module_forward_matches_fused_step():
