@@ -14,25 +14,43 @@ namespace rln {
 // BatchNorm bookkeeping
 // =============================================================================================
 
-// one wave per channel: sums the per-block partials in double
-__global__ __launch_bounds__(256) void bn_finalize_k(const float* __restrict__ partial, long long nblk, int J,
-                                                     double count, float eps, float* mean, float* var,
-                                                     float* invstd, float* stdv) {
-  const int lane = threadIdx.x & 63;
-  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (j >= J) return;
-  double s1 = 0.0, s2 = 0.0;
-#pragma unroll 8
-  for (long long b = lane; b < nblk; b += 64) {
-    s1 += (double)partial[(b * J + j) * 2 + 0];
-    s2 += (double)partial[(b * J + j) * 2 + 1];
+// Column sums of the [nblk][J][2] partial rows for channel j by one 256-thread block, in double and in a fixed order
+// (thread t: rows t, t + 256, ...; butterfly inside the wave; waves 0..3).  These reductions sit between two dependent
+// launches ~120 times per step and are pure load latency: a block per channel needs nblk / 256 rounds of loads where a
+// wave per channel needed nblk / 64 (4800 rows at 120x160: 9 -> 5 us per launch).
+__device__ __forceinline__ void block_rows_sum2(const float* __restrict__ partial, long long nblk, int J, int j, double& s1,
+                                                double& s2) {
+  __shared__ double red2[8];
+  double a = 0.0, b = 0.0;
+#pragma unroll 4
+  for (long long r = threadIdx.x; r < nblk; r += 256) {
+    const float2 v = *reinterpret_cast<const float2*>(partial + (r * J + j) * 2);
+    a += (double)v.x;
+    b += (double)v.y;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
-    s1 += __shfl_xor(s1, o, 64);
-    s2 += __shfl_xor(s2, o, 64);
+    a += __shfl_xor(a, o, 64);
+    b += __shfl_xor(b, o, 64);
   }
-  if (lane == 0) {
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    red2[w * 2 + 0] = a;
+    red2[w * 2 + 1] = b;
+  }
+  __syncthreads();
+  s1 = ((red2[0] + red2[2]) + red2[4]) + red2[6];
+  s2 = ((red2[1] + red2[3]) + red2[5]) + red2[7];
+}
+
+// one block per channel
+__global__ __launch_bounds__(256) void bn_finalize_k(const float* __restrict__ partial, long long nblk, int J,
+                                                     double count, float eps, float* mean, float* var,
+                                                     float* invstd, float* stdv) {
+  const int j = blockIdx.x;
+  double s1, s2;
+  block_rows_sum2(partial, nblk, J, j, s1, s2);
+  if (threadIdx.x == 0) {
     const double m = s1 / count;
     double v = s2 / count - m * m;
     if (v < 0.0) v = 0.0;
@@ -45,32 +63,23 @@ __global__ __launch_bounds__(256) void bn_finalize_k(const float* __restrict__ p
 }
 
 // bn_finalize of the channels a layer has just written + bn_prep of the NEXT layer's BatchNorm over its whole input
-// range, in one launch (they are adjacent in the stream and each costs a dependent-dispatch gap).  One wave per
-// channel c of the next BatchNorm; channels [new_lo, new_lo + Jnew) are the new ones.  Same arithmetic and
-// summation order as the two stand-alone kernels.
+// range, in one launch (they are adjacent in the stream and each costs a dependent-dispatch gap).  Blocks [0, Jnew):
+// one block per new channel new_lo + blockIdx.x (statistics from the partial rows, then its table entry); the blocks
+// after them: one thread per channel that already has statistics.
 __global__ __launch_bounds__(256) void bn_finalize_prep_k(const float* __restrict__ partial, long long nblk, int Jnew,
                                                           int new_lo, double count, float eps, float* mean, float* var,
                                                           float* invstd, float* stdv, int C,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* running_mean, float* running_var, float momentum,
                                                           float unbias, float* a, float* b) {
-  const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c >= C) return;
   float m, vr, is;
-  const int j = c - new_lo;
-  if (j >= 0 && j < Jnew) {
-    double s1 = 0.0, s2 = 0.0;
-#pragma unroll 8
-    for (long long bb = lane; bb < nblk; bb += 64) {
-      s1 += (double)partial[(bb * Jnew + j) * 2 + 0];
-      s2 += (double)partial[(bb * Jnew + j) * 2 + 1];
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      s1 += __shfl_xor(s1, o, 64);
-      s2 += __shfl_xor(s2, o, 64);
-    }
+  int c;
+  if ((int)blockIdx.x < Jnew) {
+    const int j = blockIdx.x;
+    c = new_lo + j;
+    double s1, s2;
+    block_rows_sum2(partial, nblk, Jnew, j, s1, s2);
+    if (threadIdx.x != 0) return;
     const double md = s1 / count;
     double v = s2 / count - md * md;
     if (v < 0.0) v = 0.0;
@@ -78,25 +87,24 @@ __global__ __launch_bounds__(256) void bn_finalize_prep_k(const float* __restric
     vr = (float)v;
     const float sd = sqrtf(vr + eps);
     is = 1.0f / sd;
-    if (lane == 0) {
-      mean[c] = m;
-      var[c] = vr;
-      invstd[c] = is;
-      stdv[c] = sd;
-    }
+    mean[c] = m;
+    var[c] = vr;
+    invstd[c] = is;
+    stdv[c] = sd;
   } else {
+    const int i = ((int)blockIdx.x - Jnew) * 256 + threadIdx.x;  // index among the C - Jnew older channels
+    if (i >= C - Jnew) return;
+    c = i < new_lo ? i : i + Jnew;
     m = mean[c];
     vr = var[c];
     is = invstd[c];
   }
-  if (lane == 0) {
-    const float av = gamma[c] * is;
-    a[c] = av;
-    b[c] = beta[c] - m * av;
-    if (running_mean != nullptr) {
-      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
-      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (vr * unbias);
-    }
+  const float av = gamma[c] * is;
+  a[c] = av;
+  b[c] = beta[c] - m * av;
+  if (running_mean != nullptr) {
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (vr * unbias);
   }
 }
 
@@ -104,14 +112,14 @@ int bn_finalize_prep(const float* partial, long long nblk, int Jnew, int new_lo,
                      float* var, float* invstd, float* stdv, int C, const float* gamma, const float* beta,
                      float* running_mean, float* running_var, float momentum, float* a, float* b, hipStream_t s) {
   const float unbias = count > 1.0 ? (float)(count / (count - 1.0)) : 1.0f;
-  hipLaunchKernelGGL(bn_finalize_prep_k, dim3((C + 3) / 4), dim3(256), 0, s, partial, nblk, Jnew, new_lo, count, eps,
+  hipLaunchKernelGGL(bn_finalize_prep_k, dim3((unsigned)(Jnew + (C - Jnew + 255) / 256)), dim3(256), 0, s, partial, nblk, Jnew, new_lo, count, eps,
                      mean, var, invstd, stdv, C, gamma, beta, running_mean, running_var, momentum, unbias, a, b);
   RLN_LAUNCH_CHECK();
 }
 
 int bn_finalize(const float* partial, long long nblk, int J, double count, float eps, float* mean, float* var,
                 float* invstd, float* stdv, hipStream_t s) {
-  hipLaunchKernelGGL(bn_finalize_k, dim3((J + 3) / 4), dim3(256), 0, s, partial, nblk, J, count, eps, mean, var,
+  hipLaunchKernelGGL(bn_finalize_k, dim3((unsigned)J), dim3(256), 0, s, partial, nblk, J, count, eps, mean, var,
                      invstd, stdv);
   RLN_LAUNCH_CHECK();
 }
@@ -149,24 +157,13 @@ int bn_prep(int training, int C, const float* gamma, const float* beta, const fl
   RLN_LAUNCH_CHECK();
 }
 
-__device__ __forceinline__ void bn_bwd_finalize_body(int vb, const float* __restrict__ partial, long long nblk, int J,
+// one block per channel j (block_rows_sum2)
+__device__ __forceinline__ void bn_bwd_finalize_body(int j, const float* __restrict__ partial, long long nblk, int J,
                                                      const float* __restrict__ gamma, float* dgamma, float* dbeta,
                                                      float* S1, float* S2) {
-  const int lane = threadIdx.x & 63;
-  const int j = vb * 4 + (threadIdx.x >> 6);
-  if (j >= J) return;
-  double s1 = 0.0, s2 = 0.0;
-#pragma unroll 8
-  for (long long b = lane; b < nblk; b += 64) {
-    s1 += (double)partial[(b * J + j) * 2 + 0];
-    s2 += (double)partial[(b * J + j) * 2 + 1];
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    s1 += __shfl_xor(s1, o, 64);
-    s2 += __shfl_xor(s2, o, 64);
-  }
-  if (lane == 0) {
+  double s1, s2;
+  block_rows_sum2(partial, nblk, J, j, s1, s2);
+  if (threadIdx.x == 0) {
     dbeta[j] = (float)s1;
     dgamma[j] = (float)s2;
     const float g = gamma[j];
@@ -183,7 +180,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_k(const float* __restrict
 
 int bn_bwd_finalize(const float* partial, long long nblk, int J, const float* gamma, float* dgamma, float* dbeta,
                     float* S1, float* S2, hipStream_t s) {
-  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((J + 3) / 4), dim3(256), 0, s, partial, nblk, J, gamma, dgamma, dbeta, S1,
+  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((unsigned)J), dim3(256), 0, s, partial, nblk, J, gamma, dgamma, dbeta, S1,
                      S2);
   RLN_LAUNCH_CHECK();
 }
@@ -402,7 +399,7 @@ __global__ __launch_bounds__(256) void dense_tail_k(const DenseTail t) {
 static inline bool rows_tall(long long rows, long long len) { return len <= 4096 && rows >= 64; }
 
 int dense_tail(DenseTail t, hipStream_t s) {
-  t.nA = (t.J + 3) / 4;
+  t.nA = t.J;  // one block per channel (bn_bwd_finalize_body)
   t.w_tall = rows_tall(t.w_rows, t.w_len) ? 1 : 0;
   t.b_tall = rows_tall(t.b_rows, t.b_len) ? 1 : 0;
   t.nB = t.w_tall ? (t.w_len + 3) / 4 : (t.w_len + 255) / 256;
