@@ -3232,6 +3232,91 @@ int rln_op_dense3_fwd(const float* x, int n, int cin, int x_ctot, int x_coff, in
   return 0;
 }
 
+int rln_op_dense3_fwd_pair(float* stack, int n, int cin, int ctot, int coff, int h, int w, const float* a1,
+                           const float* b1, const float* w1, const float* bias1, const float* scale1, const float* a2,
+                           const float* b2, const float* w2, const float* bias2, const float* scale2, float* stats1,
+                           float* stats2, int dtype, float* scratch, void* workspace, size_t workspace_bytes,
+                           void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!stack || !a1 || !b1 || !w1 || !a2 || !b2 || !w2 || !scratch || !workspace) return fail(RLN_ERR_ARG, "null pointer");
+  if (dtype < 0 || dtype > 1) return fail(RLN_ERR_ARG, "dtype 0 (bf16) or 1 (f16)");
+  if (cin < 16 || (cin % 16) != 0 || coff + cin + 32 > ctot)
+    return fail(RLN_ERR_ARG, "cin a multiple of 16 and room for 32 new channels after the input range");
+  const size_t plane = (size_t)h * w;
+  const int cout = 16, parts = 1;
+  D3Fwd p;
+  memset(&p, 0, sizeof(p));
+  p.S = stack + (size_t)coff * plane;
+  p.ns = (long long)ctot * plane;
+  p.cs = (int)plane;
+  p.H = h;
+  p.W = w;
+  p.Cin = cin;
+  p.pa = a1;
+  p.pb = b1;
+  p.bias = bias1;
+  p.nscale = scale1;
+  p.out = stack + (size_t)(coff + cin) * plane;
+  p.out_ns = p.ns;
+  p.out_cs = (int)plane;
+  p.Cout = cout;
+  p.ksplit = 1;
+  if (!d3_fwd_supported(p)) return fail(RLN_ERR_UNSUPPORTED, "geometry not covered by the dense3 forward kernel");
+  d3_fwd_pick_tile(h, w, parts, &p.th, &p.tw, &p.rg);
+  p.tiles_y = (h + p.th - 1) / p.th;
+  p.tiles_x = (w + p.tw - 1) / p.tw;
+  // workspace: [2 descriptors | packed weights of both layers | statistics partials]
+  Carver cv(workspace);
+  D3PackDesc* desc = cv.take<D3PackDesc>(2);
+  const long long e1 = d3_pack_entries(cin, parts), e2 = d3_pack_entries(cin + 16, parts);
+  uint4* packed1 = cv.take<uint4>((size_t)e1);
+  uint4* packed2 = cv.take<uint4>((size_t)e2);
+  const long long nblk = (long long)n * p.tiles_x * p.tiles_y;
+  float* partial = (stats1 || stats2) ? cv.take<float>((size_t)nblk * cout * 2) : nullptr;
+  if (cv.off > workspace_bytes) return fail(RLN_ERR_WORKSPACE, "workspace of %zu bytes needed", cv.off);
+  const float* wts[2] = {w1, w2};
+  uint4* pks[2] = {packed1, packed2};
+  for (int i = 0; i < 2; ++i) {  // the weights may live anywhere: each is described relative to itself
+    D3PackDesc d;
+    d.w_off = 0;
+    d.cin = cin + 16 * i;
+    d.cout = cout;
+    d.wf_off = 0;
+    d.wb_off = -1;
+    d.unit_begin = 0;
+    d.n_units = 5 * ((d.cin + 15) / 16);
+    hipError_t e = hipMemcpyAsync(desc + i, &d, sizeof(d), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);  // `d` is a stack object
+    if (e != hipSuccess) return fail((int)e, "descriptor upload failed");
+    RLN_TRY(d3_pack_weights(wts[i], desc + i, 1, d.n_units, pks[i], parts, dtype, s));
+  }
+  // layer 1 complete + layer 2's raw sums over the shared chunks
+  D3Fwd q = p;
+  q.wpk = packed1;
+  q.stat_partial = stats1 ? partial : nullptr;
+  q.pa2 = a2;
+  q.pb2 = b2;
+  q.wpk2 = packed2;
+  q.partial_out = scratch;
+  RLN_TRY(d3_fwd_pair_launch(q, n, parts, dtype, s));
+  if (stats1) RLN_TRY(reduce_rows(partial, nblk, (long long)cout * 2, stats1, s));
+  // layer 2: its last chunk (layer 1's output) on top of the raw sums
+  D3Fwd f = p;
+  f.Cin = cin + 16;
+  f.pa = a2;
+  f.pb = b2;
+  f.wpk = packed2;
+  f.bias = bias2;
+  f.nscale = scale2;
+  f.out = stack + (size_t)(coff + cin + 16) * plane;
+  f.stat_partial = stats2 ? partial : nullptr;
+  f.c_first = cin / 16;
+  f.partial_in = scratch;
+  RLN_TRY(d3_fwd_launch(f, n, parts, dtype, s));
+  if (stats2) RLN_TRY(reduce_rows(partial, nblk, (long long)cout * 2, stats2, s));
+  return 0;
+}
+
 int rln_op_convt(const float* x, int n, int cin, int h, int w, const float* weight, const float* bias, int cout,
                  float* out, int out_ctot, int out_coff, int hout, int wout, void* stream) {
   if (hout > 2 * h + 1 || wout > 2 * w + 1) return fail(RLN_ERR_ARG, "crop larger than the transposed conv output");

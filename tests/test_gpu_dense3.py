@@ -142,3 +142,55 @@ def test_bf16_operand_mode_mask_agreement():
     assert res[(2, "f16")][0] == 1.0 and res[(2, "f16")][1] < 1e-3      # the default (fp32-parity) arithmetic
     assert res[(1, "bf16")][0] > 0.99 and res[(1, "bf16")][1] < 5e-2     # plain bf16 operands: measured shortfall
     assert res[(1, "f16")][0] > 0.999
+
+
+@pytest.mark.parametrize("h,w", [(8, 40), (16, 80), (30, 40), (24, 160), (13, 44), (60, 80), (9, 96), (33, 120)])
+@pytest.mark.parametrize("cin", [16, 48, 112, 208])
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_dense3_forward_pair_equals_two_single_launches(h, w, cin, dtype):
+    """Two consecutive layers of a block in one pass over their shared input channels (d3_fwd2_k + the one-chunk
+    finishing launch) against two one-layer launches on the same one-part operands: the same products, summed in a
+    different order (shared chunks first, then the chunk layer 1 has just written), so the outputs agree to fp32
+    summation noise; statistics and untouched channels as in the one-layer test."""
+    if cin == 208 and (h, w) not in [(16, 80), (24, 160), (13, 44)]:
+        pytest.skip("large-K case runs on three geometries")
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(h * 1000 + w + cin + dtype)
+    n, coff = 2, 4
+    ctot = coff + cin + 32 + 4
+    x = torch.randn(n, ctot, h, w, generator=g)
+    a1 = torch.rand(cin, generator=g) + 0.5
+    b1 = torch.randn(cin, generator=g) * 0.3
+    a2 = torch.rand(cin + 16, generator=g) + 0.5
+    b2 = torch.randn(cin + 16, generator=g) * 0.3
+    w1 = torch.randn(16, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    w2 = torch.randn(16, cin + 16, 3, 3, generator=g) / (3 * (cin + 16) ** 0.5)
+    bias1 = torch.randn(16, generator=g) * 0.1
+    bias2 = torch.randn(16, generator=g) * 0.1
+    s1 = (torch.rand(n, 16, generator=g) < 0.8).float() * 1.25
+    s2 = (torch.rand(n, 16, generator=g) < 0.8).float() * 1.25
+    dev = "cuda"
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    a1d, b1d, a2d, b2d, w1d, w2d, bi1, bi2, s1d, s2d = (t.to(dev) for t in (a1, b1, a2, b2, w1, w2, bias1, bias2, s1, s2))
+    # reference: two one-layer launches, the second reading what the first wrote
+    ref = x.to(dev).clone()
+    st_ref = [torch.zeros(16, 2, device=dev) for _ in range(2)]
+    L.check(lib.rln_op_dense3_fwd(_p(ref), n, cin, ctot, coff, h, w, _p(a1d), _p(b1d), _p(w1d), _p(bi1), 16, _p(s1d),
+                                  _p(ref), ctot, coff + cin, _p(st_ref[0]), 1, dtype, _p(ws), ws.numel(), _stream()))
+    L.check(lib.rln_op_dense3_fwd(_p(ref), n, cin + 16, ctot, coff, h, w, _p(a2d), _p(b2d), _p(w2d), _p(bi2), 16,
+                                  _p(s2d), _p(ref), ctot, coff + cin + 16, _p(st_ref[1]), 1, dtype, _p(ws), ws.numel(),
+                                  _stream()))
+    got = x.to(dev).clone()
+    st_got = [torch.zeros(16, 2, device=dev) for _ in range(2)]
+    scratch = torch.empty(n * 16 * h * w, device=dev)
+    L.check(lib.rln_op_dense3_fwd_pair(_p(got), n, cin, ctot, coff, h, w, _p(a1d), _p(b1d), _p(w1d), _p(bi1), _p(s1d),
+                                       _p(a2d), _p(b2d), _p(w2d), _p(bi2), _p(s2d), _p(st_got[0]), _p(st_got[1]), dtype,
+                                       _p(scratch), _p(ws), ws.numel(), _stream()))
+    torch.cuda.synchronize()
+    lo = coff + cin
+    assert torch.equal(got[:, :lo], ref[:, :lo]) and torch.equal(got[:, lo + 32:], ref[:, lo + 32:])
+    assert torch.equal(got[:, lo:lo + 16], ref[:, lo:lo + 16])  # layer 1: same chunk order as the one-layer launch
+    scale = float(ref[:, lo + 16:lo + 32].abs().max())
+    assert float((got[:, lo + 16:lo + 32] - ref[:, lo + 16:lo + 32]).abs().max()) < 2e-6 * scale
+    assert torch.equal(st_got[0], st_ref[0])
+    assert torch.allclose(st_got[1], st_ref[1], rtol=1e-5, atol=1e-4)
