@@ -98,13 +98,13 @@ struct Level {
 enum ProfClass {
   PC_DENSE_FWD = 0, PC_FIRST_FWD, PC_TD_FWD, PC_TU_FWD, PC_DENSE_DGRAD, PC_TD_DGRAD, PC_TU_DGRAD, PC_DENSE_WGRAD,
   PC_FIRST_WGRAD, PC_TD_WGRAD, PC_TU_WGRAD, PC_BN, PC_GRADFIN, PC_REDUCE, PC_HEAD_FWD, PC_LOSS, PC_HEAD_BWD,
-  PC_D3_FWD, PC_D3_PULL, PC_D3_WGRAD, PC_D3_FWD_S, PC_COUNT
+  PC_D3_FWD, PC_D3_PULL, PC_D3_WGRAD, PC_D3_FWD_S, PC_D3_FWD2, PC_COUNT
 };
 static const char* kProfNames[PC_COUNT] = {
     "dense_conv3x3_fwd", "first_conv_fwd", "transition_down_fwd", "transition_up_fwd", "dense_conv3x3_dgrad",
     "transition_down_dgrad", "transition_up_dgrad", "dense_conv3x3_wgrad", "first_conv_wgrad",
     "transition_down_wgrad", "transition_up_wgrad", "bn_stats_affine", "grad_finalize", "partial_reduce",
-    "head_fwd", "loss", "head_bwd", "dense3_fwd", "dense3_dgrad_pull", "dense3_wgrad", "dense3_fwd_small"};
+    "head_fwd", "loss", "head_bwd", "dense3_fwd", "dense3_dgrad_pull", "dense3_wgrad", "dense3_fwd_small", "dense3_fwd_pair"};
 struct ProfEntry {
   hipEvent_t a, b;
   int cls;
@@ -1088,7 +1088,7 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
           q2.partial_out = c->fpair;
           const double flops = 2.0 * 2.0 * o.cin * o.cout * 9.0 * q.H * q.W * N;
           const double bytes = (double)N * q.H * q.W * (st_bytes(dl.st) * ((double)o.cin + o.cout) + 4.0 * o.cout);
-          ProfScope ps(c, q.th * q.tw > 320 ? PC_D3_FWD : PC_D3_FWD_S, flops, bytes, s);
+          ProfScope ps(c, PC_D3_FWD2, flops, bytes, s);  // its own class: one kernel symbol (d3_fwd2_k) per class
           const int e2 = d3_fwd_pair_launch(q2, N, c->d3_fwd_np, c->d3_fwd_dt, s);
           if (e2 == 0) {
             paired = true;
@@ -1101,8 +1101,10 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
       if (paired) {
         e3 = 0;
       } else {
-        const double flops = 2.0 * o.cin * o.cout * 9.0 * q.H * q.W * N;
-        const double bytes = (double)st_bytes(dl.st) * N * ((double)o.cin + o.cout) * q.H * q.W;
+        // (a finishing launch contracts only the 16 channels its partner wrote and reads the fp32 raw sums)
+        const double kin = q.partial_in ? 16.0 : (double)o.cin;
+        const double flops = 2.0 * kin * o.cout * 9.0 * q.H * q.W * N;
+        const double bytes = (double)N * q.H * q.W * (st_bytes(dl.st) * (kin + o.cout) + (q.partial_in ? 4.0 * o.cout : 0.0));
         // one class per kernel instantiation, so that a class's average launch time is a row of the rocprofv3 summary:
         // d3_fwd_k<10, ...> (tiles of up to 640 pixels: the wide levels) / d3_fwd_k<5, ...> (<= 320 pixels)
         ProfScope ps(c, q.th * q.tw > 320 ? PC_D3_FWD : PC_D3_FWD_S, flops, bytes, s);
