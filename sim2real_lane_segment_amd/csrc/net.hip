@@ -517,11 +517,15 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
   level_dims(c, h, w, hs, ws);
   Carver cv(base);
   std::vector<float*> S(nd + 1), G(nd + 1);
-  // bf16 storage: the levels the split-operand kernel families cover (rows of >= 40 pixels in whole octets: 97.5 % of
-  // the activation elements at 120x160) keep their stack as bf16 planes; the deep levels stay fp32
+  // bf16 storage: the levels the split-operand kernel families cover -- forward AND backward: rows of 40 pixels or of a
+  // multiple of 80 (d3_pull_supported; 97.5 % of the activation elements at 120x160, every level down to 30x40 at
+  // 480x640) -- keep their stack as bf16 planes; the deep levels and levels of any other width stay fp32 (a 232x312
+  // frame therefore runs the one-part bf16 arithmetic on fp32 stacks throughout: the exact-fp32 fall-back kernels of
+  // its dense blocks read fp32 planes only)
   std::vector<int> lst(nd + 1, ST_F32);
   for (int L = 0; L <= nd; ++L)
-    if (c->storage == 1 && ws[L] >= 40 && (ws[L] % 8) == 0 && hs[L] >= 4 && c->cfg.growth_rate <= 16) lst[L] = ST_BF16;
+    if (c->storage == 1 && (ws[L] == 40 || (ws[L] >= 80 && ws[L] % 80 == 0)) && hs[L] >= 4 && c->cfg.growth_rate <= 16)
+      lst[L] = ST_BF16;
   for (int L = 0; L <= nd; ++L)
     S[L] = reinterpret_cast<float*>(
         cv.take<unsigned char>((size_t)n * c->levels[L].C * hs[L] * ws[L] * (size_t)st_bytes(lst[L])));
