@@ -195,8 +195,10 @@ def inference_bench(dev, build, h=480, w=640):
                        f"built once (rln_set_eval_cache), every conv / activation / softmax of the forward in the timed loop",
            "unit": "frames/sec"}
     x16, _ = make_batch(16, h, w, seed=7, device=dev, work_device=dev)
-    for storage in ("f32", "bf16"):
-        model, eng = build(storage)
+    # f32: the parity arithmetic (f16x2 operands, fp32 stacks); f32_f16x1: fp32 stacks with ONE f16 operand part (two dense
+    # layers per launch; mask agreement with the reference 0.9997, tests/test_gpu_dense3.py); bf16: bf16 stacks + operands
+    for storage in ("f32", "f32_f16x1", "bf16"):
+        model, eng = build("f32", "f16x1", "bf16x1") if storage == "f32_f16x1" else build(storage)
         model.eval()
         eng.set_eval_cache(True)
         for n in (1, 16):
