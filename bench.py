@@ -37,6 +37,7 @@ CLASS_KERNELS = {
     "dense3_fwd": ("void rln::d3_fwd_k<10,",),
     "dense3_fwd_small": ("void rln::d3_fwd_k<5,",),
     "dense3_fwd_pair": ("void rln::d3_fwd2_k<",),
+    "dense3_fwd_finish": ("void rln::d3_fin_k<",),
     "dense3_wgrad": ("void rln::d3_wgrad_k<",),
     "dense3_dgrad_pull": ("void rln::d3_pull_k<",),
     "dense_conv3x3_fwd": ("void rln::igemm_k<3, 1, 1, 0,",),
@@ -44,7 +45,7 @@ CLASS_KERNELS = {
     "dense_conv3x3_wgrad": ("void rln::wgrad_dense_q_k<", "void rln::wgrad_k<3, 1, 1,"),
 }
 # classes that run on the 16-bit MFMA pipe with split operands: products issued per algorithmic multiply-add
-SPLIT_CLASSES = ("dense3_fwd", "dense3_fwd_small", "dense3_fwd_pair", "dense3_wgrad", "dense3_dgrad_pull")  # (dense_conv3x3_dgrad mixes the 16-bit d3_dgl_k and the exact-fp32 small-level launches)
+SPLIT_CLASSES = ("dense3_fwd", "dense3_fwd_small", "dense3_fwd_pair", "dense3_fwd_finish", "dense3_wgrad", "dense3_dgrad_pull")  # (dense_conv3x3_dgrad mixes the 16-bit d3_dgl_k and the exact-fp32 small-level launches)
 
 
 def pmc_traffic(class_name, summary=None):
@@ -150,7 +151,7 @@ def roofline_of(prof, eng, instrumented_ms, images, elapsed, args):
     total_ms = sum(p["ms"] for p in timed)
     dom = max((p for p in timed if p["flops"] > 0), key=lambda p: p["ms"])
     fwd_parts, _, bwd_parts, _ = eng.dense_arith
-    parts = fwd_parts if dom["name"] in ("dense3_fwd", "dense3_fwd_small", "dense3_fwd_pair") else bwd_parts
+    parts = fwd_parts if dom["name"] in ("dense3_fwd", "dense3_fwd_small", "dense3_fwd_pair", "dense3_fwd_finish") else bwd_parts
     products = {1: 1, 2: 3, 3: 6}.get(parts, 1) if dom["name"] in SPLIT_CLASSES else 1
     if dom["name"] == "dense3_wgrad":
         products = {1: 1, 2: 3, 3: 6}.get(eng.wgrad_parts, 1)  # rln_set_wgrad_parts

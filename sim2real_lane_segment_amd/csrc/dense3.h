@@ -74,6 +74,12 @@ int d3_fwd_pair_launch(const D3Fwd& p, int N, int np, int dt, hipStream_t s);
 bool d3_fwd_supported(const D3Fwd& p);
 void d3_fwd_pick_tile(int H, int W, int np, int* th, int* tw, int* rg, int st = 0);
 int d3_fwd_launch(const D3Fwd& p, int N, int np, int dt, hipStream_t s);
+// the finishing launch of a pair (c_first, partial_in set; exactly one chunk left) as a light 4-wave kernel on 256-pixel
+// tiles; its statistics partial rows number d3_fin_rows(H, W, N).  -4 when the geometry is not covered: the caller
+// runs d3_fwd_launch instead.
+bool d3_fin_supported(const D3Fwd& p, int np);
+long long d3_fin_rows(int H, int W, int N);
+int d3_fin_launch(const D3Fwd& p, int N, int np, int dt, hipStream_t s);
 
 // ---- weight gradient -------------------------------------------------------------------------------------------------
 // dW[o][c][tap] = sum_{n,p} dY[n][o][p] * relu(a[c]*S[n][c][p+tap] + b[c]): a GEMM whose K dimension is the pixel axis.

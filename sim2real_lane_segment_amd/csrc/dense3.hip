@@ -889,6 +889,206 @@ int d3_fwd_pair_launch(const D3Fwd& p, int N, int np, int dt, hipStream_t s) {
 }
 
 // =============================================================================================
+// finishing launch of a paired forward as its own light kernel (see dense3.h: d3_fin_launch)
+//
+// The second layer of a pair still owes the ONE chunk its partner has just written: out = epilogue(partial_in +
+// conv3x3(relu(bn(x16)))).  As a d3_fwd_k launch that is a 12-wave block per CU with nothing to overlap (73 us for
+// 157 MB at 120x160, batch 64, bf16 stacks).  Here: 4-wave blocks of one 256-pixel tile, three or more per CU; the
+// 16-channel tile (+1 halo) is staged once through BN + ReLU as a [pixel][16 channels] image, the raw sums of the
+// shared chunks are prefetched under the staging, 5 K-steps x 4 M-tiles of MFMAs per wave, the forward kernel's
+// epilogue (same arithmetic, statistics of the tensor as stored).
+// =============================================================================================
+template <int DT, int ST, int TH, int TW>
+__global__ __launch_bounds__(256, 3) void d3_fin_k(const D3Fwd p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int MPW = TH * TW / 64;
+  constexpr int P = TW + 3, ROWS = TH + 2, PLANE = ROWS * P * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lp = lane & 15, lg = lane >> 4;
+  const int bx = blockIdx.x;
+  const int tile_y = bx / p.tiles_x, tile_x = bx - tile_y * p.tiles_x;
+  const int gy0 = tile_y * TH, gx0 = tile_x * TW;
+  const int n = blockIdx.z;
+  float* red = reinterpret_cast<float*>(smem + PLANE);  // [4 waves][16][2]
+  const int cb = p.c_first * 16;
+
+  // ---- per-lane geometry, weight fragments and the raw sums of the earlier chunks (in flight under the staging) ----
+  int basem[MPW], pixoff[MPW];
+  unsigned vmask = 0;
+#pragma unroll
+  for (int m = 0; m < MPW; ++m) {
+    const int mt = wave * MPW + m;
+    {
+      const int q = mt * 16 + lp;
+      const int ty = q / TW, tx = q - ty * TW;
+      basem[m] = ((ty + 1) * P + tx + 1) * 32 + (lg & 1) * 16;
+    }
+    const int q = mt * 16 + lg * 4;
+    const int ty = q / TW, tx = q - ty * TW;
+    const int gy = gy0 + ty, gx = gx0 + tx;
+    const bool ok = gy < p.H && gx < p.W;  // W % 4 == 0: a 4-pixel group is all-in or all-out
+    vmask |= (ok ? 1u : 0u) << m;
+    pixoff[m] = ok ? gy * p.W + gx : 0;
+  }
+  const int j = lp;
+  const bool jv = j < p.Cout;
+  const int jc = jv ? j : 0;
+  float4 pin[MPW];
+  {
+    const float* pn = p.partial_in + ((long long)n * p.Cout + jc) * ((long long)p.H * p.W);
+#pragma unroll
+    for (int m = 0; m < MPW; ++m) pin[m] = *reinterpret_cast<const float4*>(pn + pixoff[m]);
+  }
+  uint4 bf[5];
+  {
+    const uint4* wp = p.wpk + (long long)p.c_first * 5 * 64 + lane;
+#pragma unroll
+    for (int s0 = 0; s0 < 5; ++s0) bf[s0] = wp[s0 * 64];
+  }
+  int toff[5];
+#pragma unroll
+  for (int s0 = 0; s0 < 5; ++s0) {
+    const int tap = min(2 * s0 + (lg >> 1), 8);
+    toff[s0] = ((tap / 3 - 1) * P + (tap % 3 - 1)) * 32;
+  }
+
+  // ---- stage the 16-channel tile: thread -> image cells (16 channels each), BN + ReLU, one 16-bit part ----
+  {
+    const SP<ST> xn = SP<ST>(p.S) + ((long long)n * p.ns + (long long)cb * p.cs);
+    float av[16], bv[16];
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) {
+      av[cc] = p.pa[cb + cc];
+      bv[cc] = p.pb[cb + cc];
+    }
+    for (int e = tid; e < ROWS * P; e += 256) {
+      const int r = e / P, col = e - r * P;
+      const int iy = gy0 - 1 + r, ix = gx0 - 1 + col;
+      const bool ok = col <= TW + 1 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      const int off = ok ? iy * p.W + ix : 0;
+      float v[16];
+#pragma unroll
+      for (int cc = 0; cc < 16; ++cc) v[cc] = xn.ld1((long long)cc * p.cs + off);
+      unsigned parts[8][1];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)  // cells outside the picture are zero AFTER the activation (the convolution's padding)
+        split2<DT, 1>(ok ? relu16<DT>(fmaf(av[2 * k], v[2 * k], bv[2 * k])) : 0.f,
+                      ok ? relu16<DT>(fmaf(av[2 * k + 1], v[2 * k + 1], bv[2 * k + 1])) : 0.f, parts[k]);
+      uint4* dst = reinterpret_cast<uint4*>(smem + e * 32);
+      dst[0] = make_uint4(parts[0][0], parts[1][0], parts[2][0], parts[3][0]);
+      dst[1] = make_uint4(parts[4][0], parts[5][0], parts[6][0], parts[7][0]);
+    }
+  }
+  __syncthreads();  // image staged
+
+  f32x4 acc[MPW];
+#pragma unroll
+  for (int m = 0; m < MPW; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    constexpr int DEPTH = 4, RING = DEPTH + 1, STEPS = 5 * MPW;
+    uint4 af[RING][1];
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) {
+      const int s0 = i / MPW, m0 = i - s0 * MPW;
+      af[i % RING][0] = *reinterpret_cast<const uint4*>(smem + basem[m0] + toff[s0]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i) {
+      const int s0 = i / MPW, m = i - s0 * MPW;
+      if (i + DEPTH < STEPS) {
+        const int s1 = (i + DEPTH) / MPW, m1 = (i + DEPTH) - s1 * MPW;
+        af[(i + DEPTH) % RING][0] = *reinterpret_cast<const uint4*>(smem + basem[m1] + toff[s1]);
+      }
+      uint4 bb[1] = {bf[s0]};
+      acc[m] = mfma_split<DT, 1>(af[i % RING], bb, acc[m]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // ---- epilogue: lane holds 4 consecutive pixels of channel j per M-tile (d3_fwd_k's arithmetic) ----
+  const float bias = (jv && p.bias) ? p.bias[j] : 0.f;
+  const float sc = (jv && p.nscale) ? p.nscale[(long long)n * p.Cout + j] : 1.f;
+  const SP<ST> outn = SP<ST>(p.out) + ((long long)n * p.out_ns + (long long)jc * p.out_cs);
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int m = 0; m < MPW; ++m) {
+    const bool ok = jv && ((vmask >> m) & 1u);
+    const float pv[4] = {pin[m].x, pin[m].y, pin[m].z, pin[m].w};
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v[r] = st_round<ST>(fmaf(acc[m][r] + pv[r], w_unscale<DT>(), bias) * sc);  // statistics of the tensor as it is stored
+      if (ok) {
+        s1 += v[r];
+        s2 += v[r] * v[r];
+      }
+    }
+    if (ok) outn.st4(pixoff[m], v[0], v[1], v[2], v[3]);
+  }
+  if (p.stat_partial != nullptr) {
+    s1 = group4_sum(s1);
+    s2 = group4_sum(s2);
+    if (lg == 0) {
+      red[(wave * 16 + lp) * 2 + 0] = s1;
+      red[(wave * 16 + lp) * 2 + 1] = s2;
+    }
+    __syncthreads();
+    if (tid < 2 * p.Cout) {
+      const int jj = tid >> 1, w2 = tid & 1;
+      const float t = red[(0 * 16 + jj) * 2 + w2] + red[(1 * 16 + jj) * 2 + w2] + red[(2 * 16 + jj) * 2 + w2] +
+                      red[(3 * 16 + jj) * 2 + w2];
+      const long long brow = (long long)n * gridDim.x + bx;
+      p.stat_partial[(brow * p.Cout + jj) * 2 + w2] = t;
+    }
+  }
+}
+
+// tiling of the finishing kernel: the 256-pixel shape that wastes fewer pixels (ties -> 8 x 32: longer rows)
+static bool d3_fin_tile16(int H, int W) {
+  const long long a0 = (long long)((H + 7) / 8) * ((W + 31) / 32), a1 = (long long)((H + 15) / 16) * ((W + 15) / 16);
+  return a1 < a0;
+}
+
+long long d3_fin_rows(int H, int W, int N) {
+  const bool t16 = d3_fin_tile16(H, W);
+  const int th = t16 ? 16 : 8, tw = t16 ? 16 : 32;
+  return (long long)N * ((H + th - 1) / th) * ((W + tw - 1) / tw);
+}
+
+bool d3_fin_supported(const D3Fwd& p, int np) {
+  if (np != 1 || p.ksplit > 1 || p.partial_in == nullptr || p.wpk == nullptr) return false;
+  if (p.Cout < 1 || p.Cout > 16 || p.c_first < 1 || p.Cin != (p.c_first + 1) * 16) return false;
+  if ((p.W & 3) || p.W < 16 || p.H < 4 || (p.cs & 3) || (p.out_cs & 3) || (p.ns & 3) || (p.out_ns & 3)) return false;
+  if ((((long long)p.H * p.W) & 3) || (reinterpret_cast<uintptr_t>(p.partial_in) & 15)) return false;
+  const uintptr_t amask = p.st == ST_BF16 ? 7 : 15;
+  if ((reinterpret_cast<uintptr_t>(p.S) & amask) || (reinterpret_cast<uintptr_t>(p.out) & amask)) return false;
+  return true;
+}
+
+template <int DT, int ST, int TH, int TW>
+static int d3_fin_launch_t(D3Fwd p, int N, hipStream_t s) {
+  constexpr int P = TW + 3, ROWS = TH + 2;
+  p.tiles_y = (p.H + TH - 1) / TH;
+  p.tiles_x = (p.W + TW - 1) / TW;
+  const size_t lds = (size_t)ROWS * P * 32 + 4 * 16 * 2 * 4;
+  hipLaunchKernelGGL((d3_fin_k<DT, ST, TH, TW>), dim3((unsigned)(p.tiles_x * p.tiles_y), 1, (unsigned)N), dim3(256), lds, s, p);
+  return (int)hipGetLastError();
+}
+
+int d3_fin_launch(const D3Fwd& p, int N, int np, int dt, hipStream_t s) {
+  if (!d3_fin_supported(p, np)) return -4;
+  const bool t16 = d3_fin_tile16(p.H, p.W);
+#define D3_FIN(DT_, ST_) return t16 ? d3_fin_launch_t<DT_, ST_, 16, 16>(p, N, s) : d3_fin_launch_t<DT_, ST_, 8, 32>(p, N, s)
+  if (p.st == ST_BF16) {
+    if (dt != D3_BF16) return -4;
+    D3_FIN(D3_BF16, ST_BF16);
+  }
+  if (dt == D3_BF16) D3_FIN(D3_BF16, ST_F32);
+  D3_FIN(D3_F16, ST_F32);
+#undef D3_FIN
+}
+
+// =============================================================================================
 // weight gradient (see dense3.h)
 //
 // 12 waves: waves 0-3 consume (wave w takes the 32-pixel K-steps w, w+4, w+8 of the 320-pixel tile: per K-step one dY

@@ -98,13 +98,13 @@ struct Level {
 enum ProfClass {
   PC_DENSE_FWD = 0, PC_FIRST_FWD, PC_TD_FWD, PC_TU_FWD, PC_DENSE_DGRAD, PC_TD_DGRAD, PC_TU_DGRAD, PC_DENSE_WGRAD,
   PC_FIRST_WGRAD, PC_TD_WGRAD, PC_TU_WGRAD, PC_BN, PC_GRADFIN, PC_REDUCE, PC_HEAD_FWD, PC_LOSS, PC_HEAD_BWD,
-  PC_D3_FWD, PC_D3_PULL, PC_D3_WGRAD, PC_D3_FWD_S, PC_D3_FWD2, PC_COUNT
+  PC_D3_FWD, PC_D3_PULL, PC_D3_WGRAD, PC_D3_FWD_S, PC_D3_FWD2, PC_D3_FIN, PC_COUNT
 };
 static const char* kProfNames[PC_COUNT] = {
     "dense_conv3x3_fwd", "first_conv_fwd", "transition_down_fwd", "transition_up_fwd", "dense_conv3x3_dgrad",
     "transition_down_dgrad", "transition_up_dgrad", "dense_conv3x3_wgrad", "first_conv_wgrad",
     "transition_down_wgrad", "transition_up_wgrad", "bn_stats_affine", "grad_finalize", "partial_reduce",
-    "head_fwd", "loss", "head_bwd", "dense3_fwd", "dense3_dgrad_pull", "dense3_wgrad", "dense3_fwd_small", "dense3_fwd_pair"};
+    "head_fwd", "loss", "head_bwd", "dense3_fwd", "dense3_dgrad_pull", "dense3_wgrad", "dense3_fwd_small", "dense3_fwd_pair", "dense3_fwd_finish"};
 struct ProfEntry {
   hipEvent_t a, b;
   int cls;
@@ -557,6 +557,7 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
         int dth, dtw, drg;
         d3_fwd_pick_tile(Hd, Wd, c->d3_fwd_np, &dth, &dtw, &drg, lst[o.dst_level]);
         stat_max = std::max(stat_max, (size_t)n * ((Hd + dth - 1) / dth) * ((Wd + dtw - 1) / dtw) * o.cout * 2);
+        if (c->d3_fwd_np == 1) stat_max = std::max(stat_max, (size_t)d3_fin_rows(Hd, Wd, n) * o.cout * 2);
       }
       if (o.type == OP_DENSE) {
         const int sp = std::max(dense_fwd_split(Hd * Wd, o.cin),
@@ -1050,6 +1051,7 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
       q.tiles_y = (q.H + q.th - 1) / q.th;
       q.tiles_x = (q.W + q.tw - 1) / q.tw;
       int e3;
+      long long fin_rows = 0;  // statistics partial rows when the finishing kernel ran (its own tiling)
       // Paired forward (dense3.h: d3_fwd_pair_launch): this layer and the next one of the block over the input channels
       // they share, one load per chunk; the next op then only adds its last chunk (c_first / partial_in).
       static const bool no_fwd_pair = rln_env("RLN_NO_FWD_PAIR") != nullptr;
@@ -1111,8 +1113,16 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
         const double bytes = (double)N * q.H * q.W * (st_bytes(dl.st) * (kin + o.cout) + (q.partial_in ? 4.0 * o.cout : 0.0));
         // one class per kernel instantiation, so that a class's average launch time is a row of the rocprofv3 summary:
         // d3_fwd_k<10, ...> (tiles of up to 640 pixels: the wide levels) / d3_fwd_k<5, ...> (<= 320 pixels)
-        ProfScope ps(c, q.th * q.tw > 320 ? PC_D3_FWD : PC_D3_FWD_S, flops, bytes, s);
-        e3 = d3_fwd_launch(q, N, c->d3_fwd_np, c->d3_fwd_dt, s);
+        static const bool no_fin = rln_env("RLN_NO_FIN") != nullptr;
+        if (q.partial_in != nullptr && !no_fin && d3_fin_supported(q, c->d3_fwd_np)) {
+          // the one chunk a pair's second layer still owes: light 4-wave kernel, several blocks per CU (dense3.h)
+          ProfScope ps(c, PC_D3_FIN, flops, bytes, s);
+          e3 = d3_fin_launch(q, N, c->d3_fwd_np, c->d3_fwd_dt, s);
+          if (e3 == 0) fin_rows = d3_fin_rows(q.H, q.W, N);
+        } else {
+          ProfScope ps(c, q.th * q.tw > 320 ? PC_D3_FWD : PC_D3_FWD_S, flops, bytes, s);
+          e3 = d3_fwd_launch(q, N, c->d3_fwd_np, c->d3_fwd_dt, s);
+        }
       }
       if (e3 != 0 && q.partial_in != nullptr) return fail(e3, "the finishing launch of a paired forward failed (op %zu)", k);
       // RLN_ERR_UNSUPPORTED from the launcher (tile / LDS budget of an unusual geometry) falls through to the exact-fp32
@@ -1129,8 +1139,8 @@ int fwd_op(rln_ctx* c, size_t k, const float* x, int training, hipStream_t s) {
       }
       if (e3 == 0) {
         if (training)
-          RLN_TRY(finalize_stats(c, o.dst_level, o.out_off, o.cout, (long long)N * q.tiles_x * q.tiles_y, s,
-                                 (long long)k));
+          RLN_TRY(finalize_stats(c, o.dst_level, o.out_off, o.cout,
+                                 fin_rows > 0 ? fin_rows : (long long)N * q.tiles_x * q.tiles_y, s, (long long)k));
         return 0;
       }
     }
@@ -3278,7 +3288,8 @@ int rln_op_dense3_fwd_pair(float* stack, int n, int cin, int ctot, int coff, int
   uint4* packed1 = cv.take<uint4>((size_t)e1);
   uint4* packed2 = cv.take<uint4>((size_t)e2);
   const long long nblk = (long long)n * p.tiles_x * p.tiles_y;
-  float* partial = (stats1 || stats2) ? cv.take<float>((size_t)nblk * cout * 2) : nullptr;
+  const long long nfin = d3_fin_rows(h, w, n);
+  float* partial = (stats1 || stats2) ? cv.take<float>((size_t)std::max(nblk, nfin) * cout * 2) : nullptr;
   if (cv.off > workspace_bytes) return fail(RLN_ERR_WORKSPACE, "workspace of %zu bytes needed", cv.off);
   const float* wts[2] = {w1, w2};
   uint4* pks[2] = {packed1, packed2};
@@ -3318,6 +3329,11 @@ int rln_op_dense3_fwd_pair(float* stack, int n, int cin, int ctot, int coff, int
   f.stat_partial = stats2 ? partial : nullptr;
   f.c_first = cin / 16;
   f.partial_in = scratch;
+  if (d3_fin_supported(f, parts)) {  // the light finishing kernel where it covers the geometry (as the engine does)
+    RLN_TRY(d3_fin_launch(f, n, parts, dtype, s));
+    if (stats2) RLN_TRY(reduce_rows(partial, nfin, (long long)cout * 2, stats2, s));
+    return 0;
+  }
   RLN_TRY(d3_fwd_launch(f, n, parts, dtype, s));
   if (stats2) RLN_TRY(reduce_rows(partial, nblk, (long long)cout * 2, stats2, s));
   return 0;
