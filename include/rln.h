@@ -209,16 +209,16 @@ int rln_op_dense3_fwd(const float* x, int n, int cin, int x_ctot, int x_coff, in
                       int out_ctot, int out_coff, float* stats, int parts, int dtype, void* workspace,
                       size_t workspace_bytes, void* stream);
 /* rln_op_dense3_fwd_pair: TWO consecutive dense layers of a block in one pass over the input channels they share
- * (csrc/dense3.h: d3_fwd_pair_launch, one-part operands).  stack [N, ctot, H, W]: layer 1 reads channels [coff, coff + cin)
+ * (csrc/dense3.h: d3_fwd_pair_launch; parts = 1 or 2 operand parts).  stack [N, ctot, H, W]: layer 1 reads channels [coff, coff + cin)
  * (cin % 16 == 0) and writes [coff + cin, +16); layer 2 reads [coff, coff + cin + 16) and writes the 16 channels after
  * them.  (a1, b1) / (a2, b2): folded affines over cin / cin + 16 channels; w1 [16, cin, 3, 3], w2 [16, cin + 16, 3, 3];
  * scale1 / scale2 [N, 16] optional; stats1 / stats2 optional [16, 2]; scratch: N * 16 * H * W floats (layer 2's raw sums
- * over the shared channels).  Results equal two rln_op_dense3_fwd calls with parts = 1 up to fp32 summation order. */
+ * over the shared channels).  Results equal two rln_op_dense3_fwd calls with the same parts up to fp32 summation order. */
 int rln_op_dense3_fwd_pair(float* stack, int n, int cin, int ctot, int coff, int h, int w, const float* a1,
                            const float* b1, const float* w1, const float* bias1, const float* scale1, const float* a2,
                            const float* b2, const float* w2, const float* bias2, const float* scale2, float* stats1,
-                           float* stats2, int dtype, float* scratch, void* workspace, size_t workspace_bytes,
-                           void* stream);
+                           float* stats2, int parts, int dtype, float* scratch, void* workspace,
+                           size_t workspace_bytes, void* stream);
 /* rln_op_td_fwd: the TransitionDown forward (layers.py:45-58: BN -> ReLU -> Conv2d 1x1 -> Dropout2d scale -> MaxPool2d(2))
  * on the 16-bit MFMA pipe with split fp32 operands (csrc/pw1.h); arguments as rln_op_conv_bnrelu with ksize 1, pool 1,
  * plus parts / dtype as rln_op_dense3_fwd.  Needs an even W and 8-byte aligned views. */

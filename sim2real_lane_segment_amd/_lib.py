@@ -66,7 +66,7 @@ _PROTOS = {
                                   c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p,
                                   c_size_t, c_void_p]),
     "rln_op_dense3_fwd_pair": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 12 +
-                               [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+                               [c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rln_op_td_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                               c_void_p, c_size_t, c_void_p]),

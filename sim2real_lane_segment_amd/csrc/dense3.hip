@@ -10,6 +10,8 @@
 
 namespace rln {
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 // =============================================================================================
 // weight packing
 // =============================================================================================
@@ -211,12 +213,13 @@ __global__ __launch_bounds__(768, 3) void d3_fwd_k(const D3Fwd p) {
     const int h_goff = (h_ok ? h_iy * p.W + h_ix : 0) + 2 * h_cp * p.cs;
     const int h_lds = ((h_ok ? h_r : 0) * P + (h_side ? p.tw + 1 : 0)) * 32 + h_cp * 4;
     constexpr int NBE = 5 * NP * 64;             // weight-fragment entries per chunk
-    constexpr int NB = (NBE + 511) / 512;        // per producer thread
 
+    // (The weight fragments do not travel through the producers: as a third member of the register set they were kept
+    // in scratch across the barrier, and every scratch reload is a vmcnt(0) -- scratch shares the counter -- that drained
+    // the chunk loads issued one iteration earlier.  The consumer waves fetch them: see wload / wstore below.)
     struct Stage {
       typename SRaw<ST>::r4 s[8];  // narrow registers until the commit widens them
       typename SRaw<ST>::r1 h[2];
-      uint4 b[NB];
     };
     Stage RA;
     // the tail chunk of a Cin that is no multiple of 16 starts at Cin-16 (see d3_pack_k): no clamping needed
@@ -226,9 +229,6 @@ __global__ __launch_bounds__(768, 3) void d3_fwd_k(const D3Fwd p) {
       if (p.dbg & 1) return;
 #endif
       const SP<ST> base = Sn + (long long)chunk_base(chunk) * p.cs;  // wave-uniform
-      const uint4* wp = p.wpk + (long long)chunk * NBE;
-#pragma unroll
-      for (int i = 0; i < NB; ++i) R.b[i] = wp[min(ptid + 512 * i, NBE - 1)];
 #pragma unroll
       for (int cc = 0; cc < 8; ++cc) R.s[cc] = base.raw4(s_off[cc]);
       R.h[0] = base.raw1(h_goff);
@@ -239,10 +239,6 @@ __global__ __launch_bounds__(768, 3) void d3_fwd_k(const D3Fwd p) {
       if (p.dbg & 2) return;
 #endif
       const int cb = chunk_base(chunk);
-      uint4* btile = reinterpret_cast<uint4*>(buf + NP * PLANE);
-#pragma unroll
-      for (int i = 0; i < NB; ++i)
-        if (ptid + 512 * i < NBE) btile[ptid + 512 * i] = R.b[i];
       if (h_ok) {
         const int c0 = cb + 2 * h_cp;
         unsigned parts[NP];
@@ -330,12 +326,32 @@ __global__ __launch_bounds__(768, 3) void d3_fwd_k(const D3Fwd p) {
       const int tap = min(2 * s + (lg >> 1), 8);
       toff[s] = ((tap / 3 - 1) * P + (tap % 3 - 1)) * 32;
     }
+    // weight fragments of a chunk: global (L2-resident, 5 KB per part) -> registers at the start of the previous chunk's
+    // MFMA phase -> the other image's fragment tile before the barrier that publishes that image
+    constexpr int NBE = 5 * NP * 64;        // weight-fragment entries per chunk
+    constexpr int NBC = (NBE + 255) / 256;  // per consumer thread
+    u32x4 wreg[NBC];  // (a native vector type: as HIP's uint4 struct the array stayed a stack object)
+    auto wload = [&](int chunk) __attribute__((always_inline)) {
+      const u32x4* wp = reinterpret_cast<const u32x4*>(p.wpk) + (long long)chunk * NBE;
+#pragma unroll
+      for (int i = 0; i < NBC; ++i) wreg[i] = wp[min(tid + 256 * i, NBE - 1)];
+    };
+    auto wstore = [&](int chunk) __attribute__((always_inline)) {
+      u32x4* bt = reinterpret_cast<u32x4*>(smem + (chunk & 1) * IMG + NP * PLANE);
+#pragma unroll
+      for (int i = 0; i < NBC; ++i)
+        if (i + 1 < NBC || tid + 256 * i < NBE) bt[tid + 256 * i] = wreg[i];
+    };
+    if (c_begin < c_end) wload(c_begin);
     lds_setup();
     __syncthreads();
+    if (c_begin < c_end) wstore(c_begin);
     __syncthreads();  // first chunk staged
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
       const unsigned char* img = smem + (chunk & 1) * IMG;
       const uint4* btile = reinterpret_cast<const uint4*>(img + NP * PLANE);
+      const int nxt = min(chunk + 1, c_end - 1);  // (the last chunk refetches its own fragments: no branch around the loads)
+      wload(nxt);
       // straight-line MFMA phase (M-tiles beyond the tile read clamped addresses and are dropped in the epilogue);
       // the fragments of step i+1 are read while step i multiplies
       // straight-line MFMA phase (M-tiles beyond the tile read clamped addresses and are dropped in the epilogue).
@@ -375,6 +391,7 @@ __global__ __launch_bounds__(768, 3) void d3_fwd_k(const D3Fwd p) {
         acc[m] = mfma_split<DT, NP>(af[i % RING], bf[s & 1], acc[m]);
         __builtin_amdgcn_sched_barrier(0);  // keep the read-ahead distance: the scheduler would sink the reads
       }
+      if (nxt != chunk) wstore(nxt);
       __syncthreads();
     }
   }
@@ -530,25 +547,25 @@ __global__ __launch_bounds__(768, 3) void d3_fwd2_k(const D3Fwd p) {
     const bool h_ok = (h_r < rows) && (h_iy >= 0) && (h_iy < p.H) && (h_ix >= 0) && (h_ix < p.W);
     const int h_goff = (h_ok ? h_iy * p.W + h_ix : 0) + 2 * h_cp * p.cs;
     const int h_lds = ((h_ok ? h_r : 0) * P + (h_side ? p.tw + 1 : 0)) * 32 + h_cp * 4;
-    constexpr int NBE = 5 * NP * 64;
-    constexpr int NB = (NBE + 511) / 512;
-    struct Stage {
+    struct Stage {  // (the weight fragments are the consumers' business: see d3_fwd_k)
       typename SRaw<ST>::r4 s[8];
       typename SRaw<ST>::r1 h[2];
-      uint4 b[NB];  // weight fragments of the chunk: layer 0's from issue(), replaced by layer 1's when layer 0's are committed
     };
     auto issue = [&](int chunk, Stage& R) __attribute__((always_inline)) {
+#ifdef RLN_DIAG
+      if (p.dbg & 1) return;
+#endif
       const SP<ST> base = Sn + (long long)chunk * 16 * p.cs;  // wave-uniform
-      const uint4* wp0 = p.wpk + (long long)chunk * NBE;
-#pragma unroll
-      for (int i = 0; i < NB; ++i) R.b[i] = wp0[min(ptid + 512 * i, NBE - 1)];
 #pragma unroll
       for (int cc = 0; cc < 8; ++cc) R.s[cc] = base.raw4(s_off[cc]);
       R.h[0] = base.raw1(h_goff);
       R.h[1] = base.raw1(h_goff + p.cs);
     };
     // item (chunk, L): the chunk's raw values through layer L's table into image L
-    auto commit = [&](int chunk, int L, Stage& R) __attribute__((always_inline)) {
+    auto commit = [&](int chunk, int L, const Stage& R) __attribute__((always_inline)) {
+#ifdef RLN_DIAG
+      if (p.dbg & 2) return;
+#endif
       const int cb = chunk * 16;
       // the image base is re-materialised as an opaque value at every call: as loop invariants the LDS addresses of the
       // four commit sites of the steady-state loop cost ~40 VGPRs (spills at the 168-register budget of 12 waves)
@@ -556,15 +573,6 @@ __global__ __launch_bounds__(768, 3) void d3_fwd2_k(const D3Fwd p) {
       asm volatile("" : "+v"(ibase));
       unsigned char* buf = smem + ibase;
       const float* tab = abtab + L * 2 * Cpad;
-      uint4* btile = reinterpret_cast<uint4*>(buf + NP * PLANE);
-#pragma unroll
-      for (int i = 0; i < NB; ++i)
-        if (ptid + 512 * i < NBE) btile[ptid + 512 * i] = R.b[i];
-      if (L == 0) {  // the same chunk's fragments of the second layer: one iteration ahead of their commit
-        const uint4* wp1 = p.wpk2 + (long long)chunk * NBE;
-#pragma unroll
-        for (int i = 0; i < NB; ++i) R.b[i] = wp1[min(ptid + 512 * i, NBE - 1)];
-      }
       if (h_ok) {
         const int c0 = cb + 2 * h_cp;
         unsigned parts[NP];
@@ -652,10 +660,30 @@ __global__ __launch_bounds__(768, 3) void d3_fwd2_k(const D3Fwd p) {
     for (int L = 0; L < 2; ++L)
 #pragma unroll
       for (int m = 0; m < MPW; ++m) acc[L][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // weight fragments of item t = (chunk t >> 1, layer t & 1): fetched by the consumers one item ahead (see d3_fwd_k)
+    constexpr int NBE = 5 * NP * 64;
+    constexpr int NBC = (NBE + 255) / 256;
+    u32x4 wreg[NBC];
+    auto wload = [&](int t) __attribute__((always_inline)) {
+      const u32x4* wp = reinterpret_cast<const u32x4*>((t & 1) ? p.wpk2 : p.wpk) + (long long)(t >> 1) * NBE;
+#pragma unroll
+      for (int i = 0; i < NBC; ++i) wreg[i] = wp[min(tid + 256 * i, NBE - 1)];
+    };
+    auto wstore = [&](int t) __attribute__((always_inline)) {
+      u32x4* bt = reinterpret_cast<u32x4*>(smem + (t & 1) * IMG + NP * PLANE);
+#pragma unroll
+      for (int i = 0; i < NBC; ++i)
+        if (i + 1 < NBC || tid + 256 * i < NBE) bt[tid + 256 * i] = wreg[i];
+    };
+    if (nck > 0) wload(0);
     lds_setup();
     __syncthreads();
+    if (nck > 0) wstore(0);
     __syncthreads();  // first item staged
     auto mma_item = [&](int ioff, f32x4 (&a)[MPW]) __attribute__((always_inline)) {
+#ifdef RLN_DIAG
+      if (p.dbg & 4) return;
+#endif
       // per-item opaque bases: hoisted out of the chunk loop, the 2 x 50 x NP fragment addresses of the two images are
       // loop invariants the register allocator spills (a scratch reload in front of every MFMA)
       asm volatile("" : "+v"(ioff));
@@ -697,9 +725,14 @@ __global__ __launch_bounds__(768, 3) void d3_fwd2_k(const D3Fwd p) {
       }
     };
     for (int c = 0; c < nck; ++c) {
+      wload(2 * c + 1);
       mma_item(0, acc[0]);
+      wstore(2 * c + 1);
       __syncthreads();
+      const int tn = min(2 * c + 2, 2 * nck - 2);  // (after the last chunk: a harmless refetch, no branch around the loads)
+      wload(tn);
       mma_item(IMG, acc[1]);
+      if (c + 1 < nck) wstore(tn);
       __syncthreads();
     }
     // ---- epilogue: layer 0 like d3_fwd_k; layer 1: raw sums over the shared chunks ----
@@ -898,7 +931,7 @@ int d3_fwd_pair_launch(const D3Fwd& p, int N, int np, int dt, hipStream_t s) {
 // shared chunks are prefetched under the staging, 5 K-steps x 4 M-tiles of MFMAs per wave, the forward kernel's
 // epilogue (same arithmetic, statistics of the tensor as stored).
 // =============================================================================================
-template <int DT, int ST, int TH, int TW>
+template <int NP, int DT, int ST, int TH, int TW>
 __global__ __launch_bounds__(256, 3) void d3_fin_k(const D3Fwd p) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int MPW = TH * TW / 64;
@@ -909,7 +942,7 @@ __global__ __launch_bounds__(256, 3) void d3_fin_k(const D3Fwd p) {
   const int tile_y = bx / p.tiles_x, tile_x = bx - tile_y * p.tiles_x;
   const int gy0 = tile_y * TH, gx0 = tile_x * TW;
   const int n = blockIdx.z;
-  float* red = reinterpret_cast<float*>(smem + PLANE);  // [4 waves][16][2]
+  float* red = reinterpret_cast<float*>(smem + NP * PLANE);  // [4 waves][16][2]
   const int cb = p.c_first * 16;
 
   // ---- per-lane geometry, weight fragments and the raw sums of the earlier chunks (in flight under the staging) ----
@@ -939,11 +972,13 @@ __global__ __launch_bounds__(256, 3) void d3_fin_k(const D3Fwd p) {
 #pragma unroll
     for (int m = 0; m < MPW; ++m) pin[m] = *reinterpret_cast<const float4*>(pn + pixoff[m]);
   }
-  uint4 bf[5];
+  uint4 bf[5][NP];
   {
-    const uint4* wp = p.wpk + (long long)p.c_first * 5 * 64 + lane;
+    const uint4* wp = p.wpk + (long long)p.c_first * 5 * NP * 64 + lane;
 #pragma unroll
-    for (int s0 = 0; s0 < 5; ++s0) bf[s0] = wp[s0 * 64];
+    for (int s0 = 0; s0 < 5; ++s0)
+#pragma unroll
+      for (int pt = 0; pt < NP; ++pt) bf[s0][pt] = wp[(s0 * NP + pt) * 64];
   }
   int toff[5];
 #pragma unroll
@@ -969,14 +1004,17 @@ __global__ __launch_bounds__(256, 3) void d3_fin_k(const D3Fwd p) {
       float v[16];
 #pragma unroll
       for (int cc = 0; cc < 16; ++cc) v[cc] = xn.ld1((long long)cc * p.cs + off);
-      unsigned parts[8][1];
+      unsigned parts[8][NP];
 #pragma unroll
       for (int k = 0; k < 8; ++k)  // cells outside the picture are zero AFTER the activation (the convolution's padding)
-        split2<DT, 1>(ok ? relu16<DT>(fmaf(av[2 * k], v[2 * k], bv[2 * k])) : 0.f,
-                      ok ? relu16<DT>(fmaf(av[2 * k + 1], v[2 * k + 1], bv[2 * k + 1])) : 0.f, parts[k]);
-      uint4* dst = reinterpret_cast<uint4*>(smem + e * 32);
-      dst[0] = make_uint4(parts[0][0], parts[1][0], parts[2][0], parts[3][0]);
-      dst[1] = make_uint4(parts[4][0], parts[5][0], parts[6][0], parts[7][0]);
+        split2<DT, NP>(ok ? relu16<DT>(fmaf(av[2 * k], v[2 * k], bv[2 * k])) : 0.f,
+                       ok ? relu16<DT>(fmaf(av[2 * k + 1], v[2 * k + 1], bv[2 * k + 1])) : 0.f, parts[k]);
+#pragma unroll
+      for (int pt = 0; pt < NP; ++pt) {
+        uint4* dst = reinterpret_cast<uint4*>(smem + pt * PLANE + e * 32);
+        dst[0] = make_uint4(parts[0][pt], parts[1][pt], parts[2][pt], parts[3][pt]);
+        dst[1] = make_uint4(parts[4][pt], parts[5][pt], parts[6][pt], parts[7][pt]);
+      }
     }
   }
   __syncthreads();  // image staged
@@ -986,11 +1024,13 @@ __global__ __launch_bounds__(256, 3) void d3_fin_k(const D3Fwd p) {
   for (int m = 0; m < MPW; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
   {
     constexpr int DEPTH = 4, RING = DEPTH + 1, STEPS = 5 * MPW;
-    uint4 af[RING][1];
+    uint4 af[RING][NP];
 #pragma unroll
     for (int i = 0; i < DEPTH; ++i) {
       const int s0 = i / MPW, m0 = i - s0 * MPW;
-      af[i % RING][0] = *reinterpret_cast<const uint4*>(smem + basem[m0] + toff[s0]);
+#pragma unroll
+      for (int pt = 0; pt < NP; ++pt)
+        af[i % RING][pt] = *reinterpret_cast<const uint4*>(smem + pt * PLANE + basem[m0] + toff[s0]);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -998,10 +1038,11 @@ __global__ __launch_bounds__(256, 3) void d3_fin_k(const D3Fwd p) {
       const int s0 = i / MPW, m = i - s0 * MPW;
       if (i + DEPTH < STEPS) {
         const int s1 = (i + DEPTH) / MPW, m1 = (i + DEPTH) - s1 * MPW;
-        af[(i + DEPTH) % RING][0] = *reinterpret_cast<const uint4*>(smem + basem[m1] + toff[s1]);
+#pragma unroll
+        for (int pt = 0; pt < NP; ++pt)
+          af[(i + DEPTH) % RING][pt] = *reinterpret_cast<const uint4*>(smem + pt * PLANE + basem[m1] + toff[s1]);
       }
-      uint4 bb[1] = {bf[s0]};
-      acc[m] = mfma_split<DT, 1>(af[i % RING], bb, acc[m]);
+      acc[m] = mfma_split<DT, NP>(af[i % RING], bf[s0], acc[m]);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -1056,7 +1097,7 @@ long long d3_fin_rows(int H, int W, int N) {
 }
 
 bool d3_fin_supported(const D3Fwd& p, int np) {
-  if (np != 1 || p.ksplit > 1 || p.partial_in == nullptr || p.wpk == nullptr) return false;
+  if (np < 1 || np > 2 || p.ksplit > 1 || p.partial_in == nullptr || p.wpk == nullptr) return false;
   if (p.Cout < 1 || p.Cout > 16 || p.c_first < 1 || p.Cin != (p.c_first + 1) * 16) return false;
   if ((p.W & 3) || p.W < 16 || p.H < 4 || (p.cs & 3) || (p.out_cs & 3) || (p.ns & 3) || (p.out_ns & 3)) return false;
   if ((((long long)p.H * p.W) & 3) || (reinterpret_cast<uintptr_t>(p.partial_in) & 15)) return false;
@@ -1065,26 +1106,31 @@ bool d3_fin_supported(const D3Fwd& p, int np) {
   return true;
 }
 
-template <int DT, int ST, int TH, int TW>
+template <int NP, int DT, int ST, int TH, int TW>
 static int d3_fin_launch_t(D3Fwd p, int N, hipStream_t s) {
   constexpr int P = TW + 3, ROWS = TH + 2;
   p.tiles_y = (p.H + TH - 1) / TH;
   p.tiles_x = (p.W + TW - 1) / TW;
-  const size_t lds = (size_t)ROWS * P * 32 + 4 * 16 * 2 * 4;
-  hipLaunchKernelGGL((d3_fin_k<DT, ST, TH, TW>), dim3((unsigned)(p.tiles_x * p.tiles_y), 1, (unsigned)N), dim3(256), lds, s, p);
+  const size_t lds = (size_t)NP * ROWS * P * 32 + 4 * 16 * 2 * 4;
+  hipLaunchKernelGGL((d3_fin_k<NP, DT, ST, TH, TW>), dim3((unsigned)(p.tiles_x * p.tiles_y), 1, (unsigned)N), dim3(256), lds, s, p);
   return (int)hipGetLastError();
 }
 
 int d3_fin_launch(const D3Fwd& p, int N, int np, int dt, hipStream_t s) {
   if (!d3_fin_supported(p, np)) return -4;
   const bool t16 = d3_fin_tile16(p.H, p.W);
-#define D3_FIN(DT_, ST_) return t16 ? d3_fin_launch_t<DT_, ST_, 16, 16>(p, N, s) : d3_fin_launch_t<DT_, ST_, 8, 32>(p, N, s)
+#define D3_FIN(NP_, DT_, ST_) \
+  return t16 ? d3_fin_launch_t<NP_, DT_, ST_, 16, 16>(p, N, s) : d3_fin_launch_t<NP_, DT_, ST_, 8, 32>(p, N, s)
   if (p.st == ST_BF16) {
-    if (dt != D3_BF16) return -4;
-    D3_FIN(D3_BF16, ST_BF16);
+    if (dt != D3_BF16 || np != 1) return -4;
+    D3_FIN(1, D3_BF16, ST_BF16);
   }
-  if (dt == D3_BF16) D3_FIN(D3_BF16, ST_F32);
-  D3_FIN(D3_F16, ST_F32);
+  if (np == 2) {
+    if (dt == D3_BF16) D3_FIN(2, D3_BF16, ST_F32);
+    D3_FIN(2, D3_F16, ST_F32);
+  }
+  if (dt == D3_BF16) D3_FIN(1, D3_BF16, ST_F32);
+  D3_FIN(1, D3_F16, ST_F32);
 #undef D3_FIN
 }
 

@@ -3251,15 +3251,16 @@ int rln_op_dense3_fwd(const float* x, int n, int cin, int x_ctot, int x_coff, in
 int rln_op_dense3_fwd_pair(float* stack, int n, int cin, int ctot, int coff, int h, int w, const float* a1,
                            const float* b1, const float* w1, const float* bias1, const float* scale1, const float* a2,
                            const float* b2, const float* w2, const float* bias2, const float* scale2, float* stats1,
-                           float* stats2, int dtype, float* scratch, void* workspace, size_t workspace_bytes,
-                           void* stream) {
+                           float* stats2, int parts, int dtype, float* scratch, void* workspace,
+                           size_t workspace_bytes, void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  if (parts < 1 || parts > 2) return fail(RLN_ERR_ARG, "parts 1 or 2");
   if (!stack || !a1 || !b1 || !w1 || !a2 || !b2 || !w2 || !scratch || !workspace) return fail(RLN_ERR_ARG, "null pointer");
   if (dtype < 0 || dtype > 1) return fail(RLN_ERR_ARG, "dtype 0 (bf16) or 1 (f16)");
   if (cin < 16 || (cin % 16) != 0 || coff + cin + 32 > ctot)
     return fail(RLN_ERR_ARG, "cin a multiple of 16 and room for 32 new channels after the input range");
   const size_t plane = (size_t)h * w;
-  const int cout = 16, parts = 1;
+  const int cout = 16;
   D3Fwd p;
   memset(&p, 0, sizeof(p));
   p.S = stack + (size_t)coff * plane;
@@ -3315,6 +3316,9 @@ int rln_op_dense3_fwd_pair(float* stack, int n, int cin, int ctot, int coff, int
   q.pb2 = b2;
   q.wpk2 = packed2;
   q.partial_out = scratch;
+#ifdef RLN_DIAG
+  if (rln_env("RLN_D3_DBG")) q.dbg = atoi(rln_env("RLN_D3_DBG"));
+#endif
   RLN_TRY(d3_fwd_pair_launch(q, n, parts, dtype, s));
   if (stats1) RLN_TRY(reduce_rows(partial, nblk, (long long)cout * 2, stats1, s));
   // layer 2: its last chunk (layer 1's output) on top of the raw sums

@@ -146,8 +146,8 @@ def test_bf16_operand_mode_mask_agreement():
 
 @pytest.mark.parametrize("h,w", [(8, 40), (16, 80), (30, 40), (24, 160), (13, 44), (60, 80), (9, 96), (33, 120)])
 @pytest.mark.parametrize("cin", [16, 48, 112, 208])
-@pytest.mark.parametrize("dtype", [0, 1])
-def test_dense3_forward_pair_equals_two_single_launches(h, w, cin, dtype):
+@pytest.mark.parametrize("parts,dtype", [(1, 0), (1, 1)])
+def test_dense3_forward_pair_equals_two_single_launches(h, w, cin, parts, dtype):
     """Two consecutive layers of a block in one pass over their shared input channels (d3_fwd2_k + the one-chunk
     finishing launch) against two one-layer launches on the same one-part operands: the same products, summed in a
     different order (shared chunks first, then the chunk layer 1 has just written), so the outputs agree to fp32
@@ -155,7 +155,7 @@ def test_dense3_forward_pair_equals_two_single_launches(h, w, cin, dtype):
     if cin == 208 and (h, w) not in [(16, 80), (24, 160), (13, 44)]:
         pytest.skip("large-K case runs on three geometries")
     L, lib = _lib()
-    g = torch.Generator().manual_seed(h * 1000 + w + cin + dtype)
+    g = torch.Generator().manual_seed(h * 1000 + w + cin + dtype + parts)
     n, coff = 2, 4
     ctot = coff + cin + 32 + 4
     x = torch.randn(n, ctot, h, w, generator=g)
@@ -176,15 +176,15 @@ def test_dense3_forward_pair_equals_two_single_launches(h, w, cin, dtype):
     ref = x.to(dev).clone()
     st_ref = [torch.zeros(16, 2, device=dev) for _ in range(2)]
     L.check(lib.rln_op_dense3_fwd(_p(ref), n, cin, ctot, coff, h, w, _p(a1d), _p(b1d), _p(w1d), _p(bi1), 16, _p(s1d),
-                                  _p(ref), ctot, coff + cin, _p(st_ref[0]), 1, dtype, _p(ws), ws.numel(), _stream()))
+                                  _p(ref), ctot, coff + cin, _p(st_ref[0]), parts, dtype, _p(ws), ws.numel(), _stream()))
     L.check(lib.rln_op_dense3_fwd(_p(ref), n, cin + 16, ctot, coff, h, w, _p(a2d), _p(b2d), _p(w2d), _p(bi2), 16,
-                                  _p(s2d), _p(ref), ctot, coff + cin + 16, _p(st_ref[1]), 1, dtype, _p(ws), ws.numel(),
+                                  _p(s2d), _p(ref), ctot, coff + cin + 16, _p(st_ref[1]), parts, dtype, _p(ws), ws.numel(),
                                   _stream()))
     got = x.to(dev).clone()
     st_got = [torch.zeros(16, 2, device=dev) for _ in range(2)]
     scratch = torch.empty(n * 16 * h * w, device=dev)
     L.check(lib.rln_op_dense3_fwd_pair(_p(got), n, cin, ctot, coff, h, w, _p(a1d), _p(b1d), _p(w1d), _p(bi1), _p(s1d),
-                                       _p(a2d), _p(b2d), _p(w2d), _p(bi2), _p(s2d), _p(st_got[0]), _p(st_got[1]), dtype,
+                                       _p(a2d), _p(b2d), _p(w2d), _p(bi2), _p(s2d), _p(st_got[0]), _p(st_got[1]), parts, dtype,
                                        _p(scratch), _p(ws), ws.numel(), _stream()))
     torch.cuda.synchronize()
     lo = coff + cin
