@@ -284,13 +284,21 @@ __global__ __launch_bounds__(768, 3) void d3_fwd_k(const D3Fwd p) {
     // ~55 us a level-0 launch costs beyond its per-plane rate is NOT block turnover, and the form is not kept.)
     // chunk c_begin+i lives in set i & 1.  Iteration i (consumers multiply chunk i): commit chunk i+1 into the other
     // LDS buffer, refill its register set with chunk i+3.
+    // The prologue issues its loads unconditionally (a chunk index past the range is clamped: a redundant load nobody
+    // commits): with "if (nck > 2) issue(...)" the steady loop is entered from a join of paths with different numbers of
+    // loads in flight, and the wait-count pass then drains everything (vmcnt(0)) at the loop top of EVERY trip.
     Stage RB;
-    if (nck > 0) issue(c_begin, RA);
-    if (nck > 1) issue(c_begin + 1, RB);
+    if (nck <= 0) {  // (a split-K block without chunks: only the barriers)
+      lds_setup();
+      __syncthreads();
+      __syncthreads();
+    } else {
+    issue(c_begin, RA);
+    issue(c_begin + min(1, nck - 1), RB);
     lds_setup();
     __syncthreads();
-    if (nck > 0) commit(c_begin, bufof(0), RA);
-    if (nck > 2) issue(c_begin + 2, RA);
+    commit(c_begin, bufof(0), RA);
+    issue(c_begin + min(2, nck - 1), RA);
     __syncthreads();  // start of iteration 0
     int i = 0;
     for (; i + 4 < nck; i += 2) {  // steady state, two iterations per trip, no branches around the loads
@@ -309,6 +317,7 @@ __global__ __launch_bounds__(768, 3) void d3_fwd_k(const D3Fwd p) {
         }
       }
       __syncthreads();
+    }
     }
   } else {
     // =========================== consumer waves ===========================
@@ -609,12 +618,12 @@ __global__ __launch_bounds__(768, 3) void d3_fwd2_k(const D3Fwd p) {
     // Chunk c lives in register set c & 1.  Iteration t (consumers multiply item t) commits item t + 1:
     //   t = 2c     : (c, layer 1) from set(c); the set is free afterwards -> refill it with chunk c + 2
     //   t = 2c + 1 : (c + 1, layer 0) from set(c + 1)
-    Stage RA, RB;
-    if (nck > 0) issue(0, RA);
-    if (nck > 1) issue(1, RB);
+    Stage RA, RB;  // (nck >= 1; unconditional, clamped prologue loads: see d3_fwd_k)
+    issue(0, RA);
+    issue(min(1, nck - 1), RB);
     lds_setup();
     __syncthreads();
-    if (nck > 0) commit(0, 0, RA);
+    commit(0, 0, RA);
     __syncthreads();  // start of iteration 0
     int c = 0;
     for (; c + 3 < nck; c += 2) {  // steady state: four iterations per trip, no branches around the loads
