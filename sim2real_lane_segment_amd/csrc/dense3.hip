@@ -1288,7 +1288,9 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
       choff[cc] = ch * p.cs;
     }
     // every unit loads 8 x Raw4 (Y16: a dY unit's 16 bytes hold 8 bf16 pixels; Z8: every unit's)
-    typedef typename std::conditional<Z8, uint4, typename SRaw<ST>::r4>::type Raw4;
+    // (Z8: a native vector type -- arrays of HIP's uint4 struct in a register set that crosses the barrier were kept as
+    // stack objects, and every scratch reload is a vmcnt(0) that drains the tile loads in flight: see d3_fwd_k)
+    typedef typename std::conditional<Z8, u32x4, typename SRaw<ST>::r4>::type Raw4;
     const SP<ST> kbase(kind == 1 ? p.dY : p.S);
     const long long kns = kind == 1 ? (long long)p.Cout * p.cs : p.ns;
     const unsigned char* kbytes =
@@ -1398,7 +1400,7 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
         }
       }
       if constexpr (Z8) {  // kind 0: z = relu(a*x + b) of 8 channels x 8 bf16 pixels, once per layer of the launch
-#pragma unroll
+#pragma unroll 1  // (a real loop: unrolled, both layers' tables and parts are live at once -- 35 VGPRs over the budget)
         for (int L = 0; L < NL; ++L) {
           if (L == 1 && !sec_active) break;
           const float* ab = abtab + 32 * L;
@@ -1414,7 +1416,10 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
             unsigned parts[4][NP];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-              const float x0 = SRaw<ST_BF16>::q(rawreg[2 * k], px), x1 = SRaw<ST_BF16>::q(rawreg[2 * k + 1], px);
+              const auto& r0 = rawreg[2 * k];
+              const auto& r1 = rawreg[2 * k + 1];
+              const float x0 = SRaw<ST_BF16>::q(make_uint4(r0.x, r0.y, r0.z, r0.w), px);
+              const float x1 = SRaw<ST_BF16>::q(make_uint4(r1.x, r1.y, r1.z, r1.w), px);
               const float z0 = fmaxf(fmaf(av[2 * k], x0, bv[2 * k]), 0.f), z1 = fmaxf(fmaf(av[2 * k + 1], x1, bv[2 * k + 1]), 0.f);
               split2<DT, NP>(okf ? z0 : 0.f, okf ? z1 : 0.f, parts[k]);
             }
