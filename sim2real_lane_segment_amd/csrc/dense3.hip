@@ -809,7 +809,7 @@ void d3_fwd_pick_tile(int H, int W, int np, int* th, int* tw, int* rg, int st) {
   (void)H;
   const int pxu = 4;  // pixels per staging unit
   (void)st;
-  if (W <= 160) {  // (8 x 80 column tiles at W = 160 were measured 4 % slower than 4 x 160 strips)
+  if (W <= 160) {  // (8 x 80 column tiles at W = 160: 4 % slower than 4 x 160 strips in round 2, +0.2 ms per step again after the scratch fix of round 3)
     *tw = W;
     const int cap = np >= 3 ? 320 : 640;  // pixels per tile (LDS: two image buffers)
     int t = cap / W;
