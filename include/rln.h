@@ -209,7 +209,8 @@ int rln_op_dense3_fwd(const float* x, int n, int cin, int x_ctot, int x_coff, in
                       int out_ctot, int out_coff, float* stats, int parts, int dtype, void* workspace,
                       size_t workspace_bytes, void* stream);
 /* rln_op_dense3_fwd_pair: TWO consecutive dense layers of a block in one pass over the input channels they share
- * (csrc/dense3.h: d3_fwd_pair_launch; parts = 1 or 2 operand parts).  stack [N, ctot, H, W]: layer 1 reads channels [coff, coff + cin)
+ * (csrc/dense3.h: d3_fwd_pair_launch; parts = 1 -- parts = 2 returns RLN_ERR_UNSUPPORTED: the two-part pair kernel is
+ * written and parity-green but not instantiated, it does not fit the register budget).  stack [N, ctot, H, W]: layer 1 reads channels [coff, coff + cin)
  * (cin % 16 == 0) and writes [coff + cin, +16); layer 2 reads [coff, coff + cin + 16) and writes the 16 channels after
  * them.  (a1, b1) / (a2, b2): folded affines over cin / cin + 16 channels; w1 [16, cin, 3, 3], w2 [16, cin + 16, 3, 3];
  * scale1 / scale2 [N, 16] optional; stats1 / stats2 optional [16, 2]; scratch: N * 16 * H * W floats (layer 2's raw sums
