@@ -11,6 +11,22 @@
 namespace rln {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+// an empty "use" of a loaded register: makes the wait-count pass place the exact vmcnt for it here
+template <class T>
+__device__ __forceinline__ void touch_reg(const T& v) {
+  if constexpr (sizeof(T) == 16) {
+    const u32x4 t = __builtin_bit_cast(u32x4, v);
+    asm volatile("" ::"v"(t));
+  } else if constexpr (sizeof(T) == 8) {
+    const u32x2 t = __builtin_bit_cast(u32x2, v);
+    asm volatile("" ::"v"(t));
+  } else {
+    static_assert(sizeof(T) == 4, "register-sized value");
+    const unsigned t = __builtin_bit_cast(unsigned, v);
+    asm volatile("" ::"v"(t));
+  }
+}
 
 // =============================================================================================
 // weight packing
@@ -1301,7 +1317,7 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
     // tiles are requested strictly in order t0, t0+1, ...: a cursor replaces two integer divisions per request
     int cur_n = t0 / tiles, cur_ty = (t0 - cur_n * tiles) / p.tiles_x, cur_tx = (t0 - cur_n * tiles) - cur_ty * p.tiles_x;
     auto issue = [&](int /*t: the cursor's tile*/, Raw4 (&reg)[8], bool& okf) __attribute__((always_inline)) {
-      const int n = cur_n;
+      const int n = min(cur_n, p.N - 1);  // (a request past the last tile of the launch stays inside the tensors)
       const int gy0 = cur_ty * p.th, gx0 = cur_tx * p.tw;
       if (++cur_tx == p.tiles_x) {
         cur_tx = 0;
@@ -1341,6 +1357,10 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
       okf = ok;
     };
     auto commit = [&](int buf, const Raw4 (&rawreg)[8], bool okf) __attribute__((always_inline)) {
+      // Every thread "uses" the set's last load before the unit kinds branch: one exact vmcnt(8) on the common path.
+      // Without it the threads that own no unit never wait for their (unconditional) loads, the join leaves the set
+      // pending, and the refill below is protected by a vmcnt(0) that drains the OTHER set's loads in every iteration.
+      touch_reg(rawreg[7]);
       float4 reg[8];
       if constexpr (!Z8) {
 #pragma unroll
@@ -1466,10 +1486,16 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
     __syncthreads();  // affine table
     {
       // tile t0+i lives in set i & 1.  Iteration i (consumers multiply tile i): commit tile i+1, refill its set with i+3.
-      if (nt > 0) issue(t0, regA, okA);
-      if (nt > 1) issue(t0 + 1, regB, okB);
-      if (nt > 0) commit(0, regA, okA);
-      if (nt > 2) issue(t0 + 2, regA, okA);
+      // The prologue loads are unconditional (a request past the block's range reads a clamped, in-range tile nobody
+      // commits): conditional issues make the steady loop a join of paths with different numbers of loads in flight, and
+      // the wait-count pass then drains everything at the loop top (see d3_fwd_k).
+      if (nt <= 0) {
+        __syncthreads();
+      } else {
+      issue(t0, regA, okA);
+      issue(t0 + 1, regB, okB);
+      commit(0, regA, okA);
+      issue(t0 + 2, regA, okA);
       __syncthreads();  // first tile staged
       int i = 0;
       for (; i + 4 < nt; i += 2) {  // steady state, two iterations per trip, no branches around the loads
@@ -1488,6 +1514,7 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
           }
         }
         __syncthreads();
+      }
       }
     }
   } else {
