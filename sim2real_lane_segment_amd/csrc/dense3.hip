@@ -2232,6 +2232,10 @@ __global__ __launch_bounds__(512, 2) void d3_pull_k(const D3Pull p) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
           const bool ok = cv && ((vmask >> m) & 1u);
+          // ((x - mean) * invstd is hoisted in front of the layer loop by the compiler: 20 live registers, and the item's S
+          // loads are waited for before its first MFMA.  Made opaque per layer -- 252 VGPRs, no scratch, the wait after the
+          // first layer's 75 MFMAs -- the step did not move (fp32 +-0, bf16 +0.04 ms): the second wave of the SIMD already
+          // covers that latency.  Not kept.)
           const float xs[4] = {sv[m].x, sv[m].y, sv[m].z, sv[m].w};
 #pragma unroll
           for (int r = 0; r < 4; ++r) {

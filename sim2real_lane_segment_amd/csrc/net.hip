@@ -856,11 +856,34 @@ size_t carve(rln_ctx* c, void* base, int n, int h, int w, int with_bwd, bool ass
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // Brackets one launch (or a small group) with HIP events on the launch stream when profiling is on.
+#ifdef RLN_DIAG
+// Diagnostic builds, RLN_POISON_LDS=1: before every profiled launch each CU's LDS is filled with 0xFF (NaN patterns), so a
+// kernel that reads LDS cells it has not written shows up as changed / non-finite results (tools/poison_probe.py) instead
+// of depending on what the previous kernel -- or the previous tenant of the GPU -- left there.
+__global__ __launch_bounds__(1024) void lds_poison_k() {
+  extern __shared__ unsigned lds_words[];
+  for (int i = threadIdx.x; i < 160 * 1024 / 4; i += 1024) lds_words[i] = 0xFFFFFFFFu;
+  __syncthreads();
+  if (lds_words[(threadIdx.x * 37) % (160 * 1024 / 4)] != 0xFFFFFFFFu) __builtin_trap();  // (keeps the stores alive)
+}
+static void lds_poison(hipStream_t s) {
+  static const bool on = rln_env("RLN_POISON_LDS") != nullptr;
+  if (!on) return;
+  static DevOnce once;
+  if (once.first())
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lds_poison_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL(lds_poison_k, dim3(2048), dim3(1024), 160 * 1024, s);
+}
+#else
+static inline void lds_poison(hipStream_t) {}
+#endif
+
 struct ProfScope {
   rln_ctx* c;
   hipStream_t s;
   int idx = -1;
   ProfScope(rln_ctx* c_, int cls, double flops, double bytes, hipStream_t s_) : c(c_), s(s_) {
+    lds_poison(s);
     if (!c->prof.on) return;
     ProfEntry e;
     e.a = c->prof.get();

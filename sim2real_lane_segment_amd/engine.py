@@ -257,6 +257,11 @@ class Engine:
         need = int(self.L.rln_workspace_bytes(self.ctx, n, h, w, int(with_backward)))
         self._ws = None  # release before allocating the next one
         self._ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+        if os.environ.get("RLN_POISON_WORKSPACE"):
+            # debugging aid (tools/poison_probe.py): every byte 0xFF = NaN in fp32 and bf16.  A kernel that reads workspace
+            # it has not written in this step shows up as non-finite / changed results instead of depending on what the
+            # allocator's block happened to hold.
+            self._ws.fill_(0xFF)
         base = self._ws.data_ptr()
         aligned = (base + 255) // 256 * 256
         _lib.check(self.L.rln_set_workspace(self.ctx, ctypes.c_void_p(aligned), need, n, h, w, int(with_backward)),

@@ -382,7 +382,8 @@ def test_full_size_properties_batch64():
     p_a, _ = eng.forward(x[:32].contiguous(), training=False)
     p_a = p_a.clone()
     p_b, _ = eng.forward(x[32:].contiguous(), training=False)
-    assert torch.equal(p_all[:32], p_a) and torch.equal(p_all[32:], p_b)
+    assert torch.equal(p_all[:32], p_a), f"first half differs: max {float((p_all[:32] - p_a).abs().max()):.3e}"
+    assert torch.equal(p_all[32:], p_b), f"second half differs: max {float((p_all[32:] - p_b).abs().max()):.3e}"
     assert torch.allclose(p_all.sum(1), torch.ones_like(p_all[:, 0]), atol=1e-5)
     # training step twice with the same seed: bitwise reproducible loss and gradients (no float atomics)
     res = []
@@ -393,7 +394,11 @@ def test_full_size_properties_batch64():
         eng.backward(1.0)
         torch.cuda.synchronize()
         res.append((out.clone(), eng.grads.clone()))
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert torch.equal(res[0][0], res[1][0]), f"loss outputs differ between two identical steps: {res[0][0]} vs {res[1][0]}"
+    if not torch.equal(res[0][1], res[1][1]):
+        off = [k for k, v in eng.grad_views.items()
+               if not torch.equal(v.reshape(-1), res[0][1][v.storage_offset():v.storage_offset() + v.numel()])]
+        raise AssertionError(f"gradients differ between two identical steps in {len(off)} tensors: {off[:12]}")
     assert torch.isfinite(res[0][1]).all() and float(res[0][1].abs().max()) > 0
     # gradient linearity in loss_scale
     eng.backward(2.0)
