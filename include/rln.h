@@ -124,7 +124,9 @@ int rln_set_eval_cache(rln_ctx* ctx, int enable);
 
 /* ---- workspace -------------------------------------------------------------------------
  * Activation stacks, gradient stacks, statistics and scratch for a given input geometry.
- * The host allocates (torch caching allocator) and hands the block over. */
+ * The host allocates (torch caching allocator) and hands the block over.  rln_set_workspace is a set-up call (once per
+ * geometry): it drains the device (hipDeviceSynchronize) before it writes its descriptor tables into the block, because
+ * the block usually reuses the memory of the previous workspace while that geometry's kernels may still be in flight. */
 size_t rln_workspace_bytes(const rln_ctx* ctx, int n, int h, int w, int with_backward);
 int rln_set_workspace(rln_ctx* ctx, void* ws, size_t bytes, int n, int h, int w, int with_backward);
 

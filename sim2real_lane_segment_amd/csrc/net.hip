@@ -2582,6 +2582,15 @@ int rln_set_workspace(rln_ctx* c, void* ws, size_t bytes, int n, int h, int w, i
   const size_t need = rln_workspace_bytes(c, n, h, w, with_backward);
   if (!ws || bytes < need) return fail(RLN_ERR_WORKSPACE, "workspace of %zu bytes needed, got %zu", need, bytes);
   if (((uintptr_t)ws) & 255) return fail(RLN_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+  // The block usually reuses the memory of the previous workspace (the caching allocator hands a freed block straight
+  // back), and the descriptor tables below are written with synchronous host copies that are not ordered after the
+  // caller's stream: kernels of the previous geometry still in flight would see their activations overwritten -- a
+  // batch-64 eval forward differed from its halves by 1e-4 once in ~15 fresh-box runs (cold GPU, host far ahead).  A
+  // set-up call, once per input geometry: drain the device first.
+  {
+    const hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return fail((int)e, "hipDeviceSynchronize failed");
+  }
   carve(c, ws, n, h, w, with_backward, true);
   if (!c->d3_desc_f.empty() || !c->d3_desc_b.empty()) {  // descriptor tables of the weight-pack kernel (setup time)
     hipError_t e = hipSuccess;

@@ -255,18 +255,34 @@ class Engine:
         if self._ws_key is not None and self._ws_key[:3] == key and (self._ws_key[3] or not with_backward):
             return
         need = int(self.L.rln_workspace_bytes(self.ctx, n, h, w, int(with_backward)))
+        if self._ws is not None:
+            # kernels of the previous geometry may still be running on the block that is about to be handed back to the
+            # allocator and carved again (rln_set_workspace writes descriptor tables into it from the host)
+            torch.cuda.synchronize(self.device)
         self._ws = None  # release before allocating the next one
-        self._ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+        guard = int(os.environ.get("RLN_WS_GUARD", "0"))  # debugging aid: extra tail bytes, checked by check_ws_guard()
+        self._ws = torch.empty(need + 256 + guard, dtype=torch.uint8, device=self.device)
+        self._ws_need = need
+        if guard:
+            self._ws[-guard:].fill_(0xA5)
         if os.environ.get("RLN_POISON_WORKSPACE"):
             # debugging aid (tools/poison_probe.py): every byte 0xFF = NaN in fp32 and bf16.  A kernel that reads workspace
             # it has not written in this step shows up as non-finite / changed results instead of depending on what the
             # allocator's block happened to hold.
-            self._ws.fill_(0xFF)
+            self._ws[:need + 256].fill_(0xFF)
         base = self._ws.data_ptr()
         aligned = (base + 255) // 256 * 256
         _lib.check(self.L.rln_set_workspace(self.ctx, ctypes.c_void_p(aligned), need, n, h, w, int(with_backward)),
                    "rln_set_workspace")
         self._ws_key = (n, h, w, bool(with_backward))
+
+    def check_ws_guard(self):
+        """True when the RLN_WS_GUARD tail behind the workspace is untouched (no kernel wrote past the carved size)."""
+        guard = int(os.environ.get("RLN_WS_GUARD", "0"))
+        if not guard or self._ws is None:
+            return True
+        torch.cuda.synchronize()
+        return bool((self._ws[-guard:] == 0xA5).all())
 
     # ---- compute --------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, training: bool, with_backward: bool = False,

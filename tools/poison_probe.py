@@ -32,10 +32,19 @@ def run(poison):
         eng.set_storage("bf16")
     eng.load_state(st)
     pe = eng.forward(x, training=False)[0].clone()
+    if not eng.check_ws_guard():
+        print("GUARD BROKEN after the eval forward (a kernel wrote past the workspace)")
+    half = eng.forward(x[: max(1, n // 2)].contiguous(), training=False)[0].clone()
+    if not eng.check_ws_guard():
+        print("GUARD BROKEN after the half-batch eval forward")
+    if not torch.equal(half, pe[: max(1, n // 2)]):
+        print("half-batch eval forward differs from the full batch")
     probs, _ = eng.forward(x, training=True, with_backward=True, seed=77)
     out, _, _ = eng.loss(probs, y, weighted=True)
     eng.backward(1.0)
     torch.cuda.synchronize()
+    if not eng.check_ws_guard():
+        print("GUARD BROKEN after the training step")
     return pe, probs.clone(), out.clone(), eng.grads.clone(), eng
 
 

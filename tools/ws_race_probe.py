@@ -1,0 +1,54 @@
+"""Does re-carving the workspace race with kernels of the previous geometry?  A long device-side sleep is queued in front
+of a batch-64 eval forward, then the forward of its second half follows at once (new geometry -> new workspace on the
+same memory).  Prints how long the host spent in the second call (a set-up that drains the device first waits for the
+sleep) and whether the batch still equals its halves.  usage: python tools/ws_race_probe.py [nosync]
+(nosync: the Python-side synchronize is skipped -- with a library that does not drain the device either, the old
+behaviour)"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from oracle import fcdensenet_oracle as O  # noqa: E402  (initialiser only)
+from sim2real_lane_segment_amd.engine import Engine, NetSpec  # noqa: E402
+
+cfg = O.fcdensenet67_config(4)
+st = O.init_state(cfg, 21)
+eng = Engine(NetSpec(n_classes=4), device="cuda")
+eng.load_state(st)
+g = torch.Generator().manual_seed(5)
+x = torch.randn(64, 3, 120, 160, generator=g).cuda()
+ref_b = eng.forward(x[32:].contiguous(), training=False)[0].clone()   # reference result of the second half
+ref_all = eng.forward(x, training=False)[0].clone()
+torch.cuda.synchronize()
+print("quiet run: second half equal", torch.equal(ref_all[32:], ref_b))
+big = torch.randn(12288, 12288, device="cuda")
+t0 = time.perf_counter()
+for _ in range(40):
+    big @ big
+torch.cuda.synchronize()
+print(f"backlog = {1e3 * (time.perf_counter() - t0):.0f} ms of device work")
+if "nosync" in sys.argv:
+    real_sync = torch.cuda.synchronize
+bad = 0
+for it in range(6):
+    eng.forward(x[:2].contiguous(), training=False)  # another geometry, so that the batch-64 call re-carves too
+    torch.cuda.synchronize()
+    for _ in range(40):                               # a few hundred ms of device work in front of the forward
+        big @ big
+    if "nosync" in sys.argv:
+        torch.cuda.synchronize = lambda *a, **k: None
+    p_all = eng.forward(x, training=False)[0]
+    t0 = time.perf_counter()
+    p_b = eng.forward(x[32:].contiguous(), training=False)[0]
+    dt = time.perf_counter() - t0
+    if "nosync" in sys.argv:
+        torch.cuda.synchronize = real_sync
+    torch.cuda.synchronize()
+    ok = torch.equal(p_all[32:], p_b) and torch.equal(p_all, ref_all)
+    bad += not ok
+    print(f"iteration {it}: host time of the half-batch call {dt * 1e3:7.1f} ms; batch == reference {torch.equal(p_all, ref_all)}, "
+          f"second half equal {torch.equal(p_all[32:], p_b)}")
+print("race probe:", "CORRUPTION SEEN" if bad else "clean")
