@@ -700,3 +700,30 @@ def test_eval_cache_reuses_tables_bit_identically():
     eng.set_eval_cache(False)
     p9 = fwd()
     assert torch.equal(p8, p9) and not torch.equal(p8, p6)
+
+
+def test_workspace_recarve_is_ordered_after_inflight_kernels():
+    """A forward with a new geometry re-carves the workspace, usually on the memory the previous geometry's kernels are still
+    using when the host runs ahead (a cold GPU, or any device backlog).  rln_set_workspace used to write its descriptor
+    tables into that block with host copies that HIP does not order after the stream: 1 in ~15 fresh-box runs of the batch-64
+    property test failed.  Here a few hundred ms of device work are queued in front of a batch forward that is followed at
+    once by the forward of its second half (tools/ws_race_probe.py: the unfixed library fails this within six rounds)."""
+    cfg = O.fcdensenet67_config(4)
+    st = O.init_state(cfg, 21)
+    eng = make_engine(cfg, st)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(64, 3, 120, 160, generator=g).cuda()
+    ref_all = eng.forward(x, training=False)[0].clone()
+    ref_b = eng.forward(x[32:].contiguous(), training=False)[0].clone()
+    assert torch.equal(ref_all[32:], ref_b)
+    big = torch.randn(12288, 12288, device="cuda")
+    for it in range(6):
+        eng.forward(x[:2].contiguous(), training=False)  # another geometry: the batch forward below re-carves too
+        torch.cuda.synchronize()
+        for _ in range(24):  # ~0.6 s of device backlog in front of the forward
+            big @ big
+        p_all = eng.forward(x, training=False)[0]
+        p_b = eng.forward(x[32:].contiguous(), training=False)[0]
+        torch.cuda.synchronize()
+        assert torch.equal(p_all, ref_all), f"round {it}: the batch forward changed under a device backlog"
+        assert torch.equal(p_b, ref_b), f"round {it}: the half-batch forward after a re-carve changed"
