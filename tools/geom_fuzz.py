@@ -37,6 +37,8 @@ def run(n, h, w):
             out, _, _ = eng.loss(pt, y, weighted=True)
             eng.backward(1.0)
             torch.cuda.synchronize()
+            if not eng.check_ws_guard():  # (RLN_WS_GUARD=<bytes>: a kernel wrote past the workspace)
+                print(f"  {n}x{h}x{w} {mode}: WORKSPACE GUARD BROKEN")
             res[mode] = (pe, float(out[0]), eng.grads.clone().cpu())
         except Exception as e:  # noqa: BLE001
             print(f"  {n}x{h}x{w} {mode}: FAILED {str(e)[:200]}")
