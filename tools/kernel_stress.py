@@ -1,0 +1,54 @@
+"""Bitwise-repeatability stress of the dense forward kernels through the op-level entry points: the same launch a few
+thousand times, every result compared with the first.  A block-level race (LDS hazards between the producer and consumer
+waves, weight fragments published too late) shows up here as a sporadic difference in one tile.
+usage: python tools/kernel_stress.py [iters]"""
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from sim2real_lane_segment_amd import _lib as L  # noqa: E402
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
+lib = L.lib()
+dev = "cuda"
+P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())  # noqa: E731
+S = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)  # noqa: E731
+ws = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+
+
+def single(parts, dtype, cin, n, h, w):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(n, cin + 16, h, w, generator=g).to(dev)
+    a, b = torch.rand(cin).add(0.5).to(dev), torch.randn(cin).mul(0.3).to(dev)
+    wt = (torch.randn(16, cin, 3, 3) / (3 * cin ** 0.5)).to(dev)
+    bias = torch.zeros(16, device=dev)
+    st = torch.zeros(16, 2, device=dev)
+    ref = None
+    bad = 0
+    for it in range(iters):
+        L.check(lib.rln_op_dense3_fwd(P(x), n, cin, cin + 16, 0, h, w, P(a), P(b), P(wt), P(bias), 16, None, P(x), cin + 16, cin,
+                                      P(st), parts, dtype, P(ws), ws.numel(), S()))
+        out = x[:, cin:].clone()
+        if ref is None:
+            ref = out
+        elif not torch.equal(out, ref):
+            d = (out - ref).abs()
+            bs = torch.nonzero(d.amax(dim=(1, 2, 3)) > 0).flatten().tolist()
+            rows = torch.nonzero(d[bs[0]].amax(dim=(0, 2)) > 0).flatten().tolist()
+            cols = torch.nonzero(d[bs[0]].amax(dim=(0, 1)) > 0).flatten().tolist()
+            print(f"  iteration {it}: max diff {float(d.max()):.3e}, samples {bs[:8]}, rows {rows[:8]} ({len(rows)}), cols "
+                  f"{cols[:4]}..{cols[-2:]} ({len(cols)})")
+            bad += 1
+    print(f"single parts {parts} dtype {dtype} cin {cin} {n}x{h}x{w}: {bad} of {iters - 1} repeats differ")
+    return bad
+
+
+total = 0
+total += single(2, 1, 208, 64, 120, 160)
+total += single(1, 0, 208, 64, 120, 160)
+total += single(2, 1, 272, 16, 480, 640) if iters <= 400 else single(2, 1, 128, 64, 60, 80)
+total += single(2, 1, 48, 64, 120, 160)
+print("kernel stress:", "DIFFERENCES SEEN" if total else "clean")
