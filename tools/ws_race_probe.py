@@ -20,6 +20,7 @@ eng = Engine(NetSpec(n_classes=4), device="cuda")
 eng.load_state(st)
 g = torch.Generator().manual_seed(5)
 x = torch.randn(64, 3, 120, 160, generator=g).cuda()
+x_copy = x.clone()
 ref_b = eng.forward(x[32:].contiguous(), training=False)[0].clone()   # reference result of the second half
 ref_all = eng.forward(x, training=False)[0].clone()
 torch.cuda.synchronize()
@@ -50,6 +51,14 @@ for it in range(int(os.environ.get('ROUNDS', '12'))):
     ok = torch.equal(p_all[32:], p_b) and torch.equal(p_all, ref_all)
     bad += not ok
     if not ok:
+        da = (p_all - ref_all).abs()
+        sa = torch.nonzero(da.amax(dim=(1, 2, 3)) > 0).flatten().tolist()
+        if sa:
+            r_ = torch.nonzero(da[sa[0]].amax(dim=(0, 2)) > 0).flatten().tolist()
+            c_ = torch.nonzero(da[sa[0]].amax(dim=(0, 1)) > 0).flatten().tolist()
+            print(f"    batch forward: max diff {float(da.max()):.3e}, samples {sa[:32]} ({len(sa)}); sample {sa[0]}: rows "
+                  f"{r_[:3]}..{r_[-2:]} ({len(r_)}), cols {c_[:3]}..{c_[-2:]} ({len(c_)}), pixels {int((da[sa[0]].amax(0) > 0).sum())}; "
+                  f"input unchanged {torch.equal(x, x_copy)}")
         p_b2 = eng.forward(x[32:].contiguous(), training=False)[0].clone()   # same workspace, no re-carve
         p_all2 = eng.forward(x, training=False)[0].clone()                   # re-carves again, quiet device
         torch.cuda.synchronize()
