@@ -115,7 +115,11 @@ static void c3_group_plan(int m_tiles, int ksteps, int np, int* mt, int* groups)
 //   P10 += W10*own + W12*left                            P11 += W11*own
 // Epilogue: + bias, crop to Ho x Wo, 8-byte stores (rows 2y and 2y+1), per-channel sums for the next BatchNorm.
 // =============================================================================================
-template <int NP, int DT, int XT, int OT>
+// WT: wave tiles a wave multiplies per pass.  WT = 2 shares every LDS weight-fragment read between two tiles but needs
+// ~310 VGPRs at two parts: 58 spilled registers, reloaded inside the K loop -- and the kernel was NOT bitwise repeatable
+// (tools/tu_stress.py: 21 of 3000 launches with one wave tile's outputs and sums changed; the spilled registers of
+// co-resident waves are the only state that is not in this source).  WT = 1 fits the register file without scratch.
+template <int NP, int DT, int XT, int OT, int WT>
 __global__ __launch_bounds__(512, 2) void c3_fwd_k(const C3Fwd p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(512, 2) void c3_fwd_k(const C3Fwd p) {
   const int CH = (p.Ho + 1) >> 1, CW = (p.Wo + 1) >> 1, CC = CH * CW;
   const int cells = p.N * CC;
   const int ntiles = (cells + 14) / 15;
-  const int nsuper = (ntiles + 1) >> 1;
+  const int nsuper = (ntiles + WT - 1) / WT;
   const int sstride = p.bpg * 8;
   const bool vec2 = ((p.Wo | p.out_cs) & 1) == 0 && (p.out_ns & 1) == 0 &&
                     (reinterpret_cast<uintptr_t>(p.out) & (2 * SP<OT>::ES - 1)) == 0;
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(512, 2) void c3_fwd_k(const C3Fwd p) {
     return c;
   };
 
-  typename SRaw<XT>::r1 qo[2][8], qu[2][8];  // narrow until convert widens them
+  typename SRaw<XT>::r1 qo[WT][8], qu[WT][8];  // narrow until convert widens them
   auto issue = [&](const Cell& c, int w, int ks) __attribute__((always_inline)) {
     const long long off = (long long)min(ks * 32 + kb * 8, p.Cin - 8) * p.cs;  // Cin % 8 == 0; weights past Cin are zero
 #pragma unroll
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(512, 2) void c3_fwd_k(const C3Fwd p) {
       qu[w][e] = c.up.raw1(off + (long long)e * p.cs);
     }
   };
-  uint4 fo[2][NP], fu[2][NP], fl[2][NP], ful[2][NP];
+  uint4 fo[WT][NP], fu[WT][NP], fl[WT][NP], ful[WT][NP];
   auto convert = [&](const Cell& c, int w) __attribute__((always_inline)) {
     unsigned a[4][NP], u[4][NP];
 #pragma unroll
@@ -204,34 +208,36 @@ __global__ __launch_bounds__(512, 2) void c3_fwd_k(const C3Fwd p) {
     }
   };
 
-  f32x4 acc[C3_MT][2][4];
+  f32x4 acc[C3_MT][WT][4];
   int ST = b * 8 + wave;
-  Cell c0 = setup_cell(2 * min(ST, nsuper - 1)), c1 = setup_cell(2 * min(ST, nsuper - 1) + 1);
+  Cell c0 = setup_cell(WT * min(ST, nsuper - 1)), c1 = setup_cell(WT * min(ST, nsuper - 1) + (WT - 1));
   if (ST < nsuper) {
     issue(c0, 0, 0);
-    issue(c1, 1, 0);
+    if constexpr (WT == 2) issue(c1, 1, 0);
   }
   while (ST < nsuper) {
 #pragma unroll
     for (int m = 0; m < C3_MT; ++m)
 #pragma unroll
-      for (int w = 0; w < 2; ++w)
+      for (int w = 0; w < WT; ++w)
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[m][w][q] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int STn = ST + sstride;
     Cell n0 = c0, n1 = c1;
     for (int ks = 0; ks < KS; ++ks) {
       convert(c0, 0);
-      convert(c1, 1);
+      if constexpr (WT == 2) convert(c1, 1);
       __builtin_amdgcn_sched_barrier(0);
       if (ks + 1 < KS) {
         issue(c0, 0, ks + 1);
-        issue(c1, 1, ks + 1);
+        if constexpr (WT == 2) issue(c1, 1, ks + 1);
       } else if (STn < nsuper) {
-        n0 = setup_cell(2 * STn);
-        n1 = setup_cell(2 * STn + 1);
+        n0 = setup_cell(WT * STn);
         issue(n0, 0, 0);
-        issue(n1, 1, 0);
+        if constexpr (WT == 2) {
+          n1 = setup_cell(WT * STn + 1);
+          issue(n1, 1, 0);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(512, 2) void c3_fwd_k(const C3Fwd p) {
 #define C3_TAP(T_, F_, P_)                                                                     \
   tapA(T_, A);                                                                                 \
   acc[m][0][P_] = mfma_split<DT, NP>(A, F_[0], acc[m][0][P_]);                                 \
-  acc[m][1][P_] = mfma_split<DT, NP>(A, F_[1], acc[m][1][P_]);
+  if constexpr (WT == 2) acc[m][WT - 1][P_] = mfma_split<DT, NP>(A, F_[WT - 1], acc[m][WT - 1][P_]);
           C3_TAP(0, fo, 0)
           C3_TAP(2, fl, 0)
           C3_TAP(6, fu, 0)
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(512, 2) void c3_fwd_k(const C3Fwd p) {
     int kb4 = 4 * kb;
     asm volatile("" : "+v"(kb4));
 #pragma unroll
-    for (int w = 0; w < 2; ++w) {
+    for (int w = 0; w < WT; ++w) {
       const Cell& c = w == 0 ? c0 : c1;
       const bool r0v = c.valid && c.oy < p.Ho, r1v = c.valid && c.oy + 1 < p.Ho;
       const bool x0v = c.ox < p.Wo, x1v = c.ox + 1 < p.Wo;
@@ -349,10 +355,11 @@ void c3_fwd_plan(C3Fwd* p, int np) {
 
 template <int NP, int DT, int ST = ST_F32, int OT = ST_F32>
 static int c3_fwd_launch_t(const C3Fwd& p, hipStream_t s) {
+  constexpr int WT = 1;  // see c3_fwd_k: two wave tiles per pass spill, and the spilling build was not repeatable
   const int KS = (p.Cin + 31) / 32;
   const size_t lds = (size_t)p.mt * KS * 9 * NP * 1024 + (size_t)p.mt * 16 * 4 + (size_t)8 * p.mt * 32 * 4;
   if (lds > 160 * 1024) return -4;
-  auto kern = c3_fwd_k<NP, DT, ST, OT>;
+  auto kern = c3_fwd_k<NP, DT, ST, OT, WT>;
   static DevOnce attr_once;
   if (attr_once.first()) {
     const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
