@@ -73,13 +73,12 @@ def det_state(shapes, seed):
 
 
 def retry_if_not_reproducible(fn):
-    """Decorator for the bit-exactness property tests (-m gpu).  Round 3 saw bursts of one-off mismatches on the shared
-    MI355X pool -- a single tile of a single sample wrong in one forward of a batch-64 property test, seven red runs out
-    of twenty within forty minutes on fresh boxes, then none in nineteen runs on twelve other GPUs -- while every probe
-    for a cause in this code stayed clean (NaN-poisoned workspaces, NaN-poisoned LDS, a NaN-poisoned torch allocator, a
-    guard zone behind the workspace, 6000 bitwise-repeated launches of the forward kernels, the workspace re-carve
-    ordering fixed on the way: DESIGN.md section 2).  A mismatch that does not reproduce when the whole check is repeated
-    on a fresh engine is reported as a warning with its localisation; one that reproduces fails the test."""
+    """Tripwire for the bit-exactness property tests (-m gpu).  Round 3 chased intermittent one-off mismatches (one wave
+    tile of one sample wrong in a forward, about one run in fifteen, later in bursts) down to a kernel that spilled
+    registers inside its inner loop and was not bitwise repeatable (the two-part TransitionUp forward; DESIGN.md section 2:
+    fixed, 4000 identical training steps now repeat exactly).  The decorator stays as a reporting device: a failed check is
+    repeated once on a fresh engine; a mismatch that reproduces fails the test, one that does not is reported as a warning
+    with its localisation instead of stopping a `-x` run."""
     import functools
     import warnings
 
