@@ -382,7 +382,9 @@ __global__ __launch_bounds__(768, 3) void d3_fwd_k(const D3Fwd p) {
       // straight-line MFMA phase (M-tiles beyond the tile read clamped addresses and are dropped in the epilogue).
       // One consumer wave per SIMD: LDS latency (~200 cycles under load) is covered by reading the A fragments
       // DEPTH steps (48 MFMA cycles each at 2 parts) ahead through a register ring.
-      constexpr int DEPTH = 5, RING = DEPTH + 1, STEPS = 5 * MPW;
+      // (three parts: a 2-deep ring -- with 5 the variant needs ~190 VGPRs, and its in-loop spills made every bf16x3
+      // forward differ from the last by up to 4e-3: tools/forward_stress.py)
+      constexpr int DEPTH = NP >= 3 ? 2 : 5, RING = DEPTH + 1, STEPS = 5 * MPW;
       uint4 af[RING][NP], bf[2][NP];
 #ifdef RLN_DIAG
       if (p.dbg & 4) {

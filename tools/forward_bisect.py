@@ -10,11 +10,17 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from oracle import fcdensenet_oracle as O  # noqa: E402
 from sim2real_lane_segment_amd.engine import Engine, NetSpec  # noqa: E402
 
-iters = int(sys.argv[1]) if len(sys.argv) > 1 else 600
+iters = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 600
 cfg = O.fcdensenet67_config(4)
 st = O.init_state(cfg, 21)
-eng = Engine(NetSpec(n_classes=4), device="cuda")
+arith = [a for a in sys.argv[1:] if "," in a]
+if arith:
+    from sim2real_lane_segment_amd.engine import parse_dense_arith
+    eng = Engine(NetSpec(n_classes=4), device="cuda", dense_arith=parse_dense_arith(arith[0]))
+else:
+    eng = Engine(NetSpec(n_classes=4), device="cuda")
 eng.load_state(st)
+EVAL = "eval" in sys.argv
 g = torch.Generator().manual_seed(5)
 N, H, W = 64, 120, 160
 x = torch.randn(N, 3, H, W, generator=g).cuda()
@@ -22,7 +28,7 @@ x = torch.randn(N, 3, H, W, generator=g).cuda()
 
 def fwd():
     eng.load_state(st)
-    p = eng.forward(x, training=True, with_backward=True, seed=77)[0]
+    p = eng.forward(x, training=not EVAL, with_backward=not EVAL, seed=77)[0]
     torch.cuda.synchronize()
     return p
 
@@ -59,7 +65,7 @@ for it in range(iters):
     cl = [288, 368, 448, 528, 608, 528]
     hw = [19200, 4800, 1200, 300, 70, 15]
     stacks = sum(N * c_ * p_ * 4 for c_, p_ in zip(cl, hw))
-    mean0 = base + 2 * stacks
+    mean0 = base + (1 if EVAL else 2) * stacks
     nchan = sum(cl)
     seg = (nchan * 4 + 255) // 256 * 256
     for name, k in (("mean", 0), ("var", 1), ("invstd", 2)):
