@@ -61,6 +61,18 @@ for it in range(iters):
           f"{first % plane // (W * 4)}, byte-in-row {first % (W * 4)})")
     print("   64 MiB windows with differences:", wins[:20], "..." if len(wins) > 20 else "")
     print("   first differing planes:", planes[:48])
+    # per level stack: which channels differ (any sample): the down path fills a level's channels in layer order
+    cl_ = [288, 368, 448, 528, 608, 528]
+    hw_ = [19200, 4800, 1200, 300, 70, 15]
+    off_ = base
+    for L_ in range(6):
+        size = N * cl_[L_] * hw_[L_] * 4
+        a_ = ws[off_:off_ + size].view(torch.float32).view(N, cl_[L_], hw_[L_])
+        b_ = ws_ref[off_:off_ + size].view(torch.float32).view(N, cl_[L_], hw_[L_])
+        ch = torch.nonzero((a_ != b_).any(dim=2).any(dim=0)).flatten().tolist()
+        same = sorted(set(range(cl_[L_])) - set(ch))
+        print(f"   level {L_} stack: {len(ch)} of {cl_[L_]} channels differ; first {ch[:12]}, last {ch[-4:]}; identical: {same[:60]}")
+        off_ += size
     # statistics arrays behind the stacks (carve order: S[0..5], G[0..5], mean, var, invstd, stdv, ...; FCDenseNet67, N = 64)
     cl = [288, 368, 448, 528, 608, 528]
     hw = [19200, 4800, 1200, 300, 70, 15]
