@@ -89,8 +89,6 @@ int64_t rln_dropout_channels(const rln_ctx* ctx, int* per_call /* may be NULL, e
  *   parts = 0 : exact fp32 MFMA (v_mfma_f32_16x16x4_f32), the round-1 kernels;
  *   parts = 1..3 : 16-bit MFMA on operands split into `parts` bf16 (dtype 0) / f16 (dtype 1) parts, fp32 accumulate
  *                  (csrc/dense3.h; 2 parts = 3 products ~ 2^-17 (bf16) / 2^-22 (f16), 3 bf16 parts = 6 products < fp32 eps).
- *                  KNOWN ISSUE: with 3 parts some kernels still spill registers inside their loops and results are not
- *                  bitwise repeatable at batch 64 (up to 4e-3 between two eval forwards): experimental.
  * fwd_* selects the forward kernels, bwd_* the data / weight gradient kernels.  Call before rln_workspace_bytes. */
 int rln_set_dense_arith(rln_ctx* ctx, int fwd_parts, int fwd_dtype, int bwd_parts, int bwd_dtype);
 /* Operand parts of the dense 3x3 weight-gradient GEMMs (d3_wgrad_k).  Every entry of dW is a sum over N*H*W pixels

@@ -267,6 +267,7 @@ __global__ __launch_bounds__(512, 2) void c3_fwd_k(const C3Fwd p) {
       }
     }
     // ---- epilogue ----
+    mfma_drain();  // wait states between the MFMA chain and the first accumulator read (split16.h)
     int kb4 = 4 * kb;
     asm volatile("" : "+v"(kb4));
 #pragma unroll
@@ -545,6 +546,7 @@ __global__ __launch_bounds__(512, 2) void c3_dgrad_k(const C3Dgrad p) {
       __syncthreads();
     }
     // ---- epilogue: G = cscale * acc (overwrite) ----
+    mfma_drain();  // wait states between the MFMA chain and the first accumulator read (split16.h)
     if (live) {
       int kb4 = 4 * kb;
       asm volatile("" : "+v"(kb4));
@@ -775,6 +777,7 @@ __global__ __launch_bounds__(192 * MO, 3) void c3_wgrad_k(const C3Wgrad p) {
     step(k, arA);
     if (k + 1 < k_end) step(k + 1, arB);
   }
+mfma_drain();  // wait states between the MFMA chain and the first accumulator read (split16.h)
   // ---- store: acc[kx][j][r] = dW[c = 16*(cg*nc+j) + n16][o = 16*otile + 4*kb + r][ky][kx] ----
   if (wave_active) {
     float* dst = p.partial + (long long)range * p.Cin * p.Cout * 9;

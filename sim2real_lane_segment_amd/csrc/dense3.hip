@@ -424,6 +424,7 @@ __global__ __launch_bounds__(768, 3) void d3_fwd_k(const D3Fwd p) {
   }
 
   // ---- epilogue (consumers): lane holds 4 consecutive pixels (rows 4*lg..4*lg+3 of the M-tile) of channel lp ----
+  mfma_drain();  // wait states between the MFMA chain and the first accumulator read (split16.h)
   float s1 = 0.f, s2 = 0.f;
   const bool raw = p.ksplit > 1;
   if (!producer) {
@@ -763,6 +764,7 @@ __global__ __launch_bounds__(768, 3) void d3_fwd2_k(const D3Fwd p) {
       __syncthreads();
     }
     // ---- epilogue: layer 0 like d3_fwd_k; layer 1: raw sums over the shared chunks ----
+    mfma_drain();  // wait states between the MFMA chain and the first accumulator read (split16.h)
     const int j = lp;
     const bool jv = j < p.Cout;
     const float bias = (jv && p.bias) ? p.bias[j] : 0.f;
@@ -1074,6 +1076,7 @@ __global__ __launch_bounds__(256, 3) void d3_fin_k(const D3Fwd p) {
     }
   }
   // ---- epilogue: lane holds 4 consecutive pixels of channel j per M-tile (d3_fwd_k's arithmetic) ----
+  mfma_drain();  // wait states between the MFMA chain and the first accumulator read (split16.h)
   const float bias = (jv && p.bias) ? p.bias[j] : 0.f;
   const float sc = (jv && p.nscale) ? p.nscale[(long long)n * p.Cout + j] : 1.f;
   const SP<ST> outn = SP<ST>(p.out) + ((long long)n * p.out_ns + (long long)jc * p.out_cs);
@@ -1600,6 +1603,7 @@ __global__ __launch_bounds__(768, 3) void d3_wgrad_k(const D3Wgrad p) {
   constexpr int NT = 9 * NL;
   float4* red = reinterpret_cast<float4*>(smem);  // [4 waves][NL x 9 taps][64 lanes]
   if (!producer) {
+    mfma_drain();  // wait states between the MFMA chain and the first accumulator read (split16.h)
 #pragma unroll
     for (int L = 0; L < NL; ++L)
 #pragma unroll
@@ -1866,6 +1870,7 @@ __global__ __launch_bounds__(256, 3) void d3_dgl_k(const D3Dgl p) {
       __builtin_amdgcn_sched_barrier(0);
     }
     // ---- epilogue: lane holds 4 consecutive pixels of channel j per M-tile ----
+    mfma_drain();  // wait states between the MFMA chain and the first accumulator read (split16.h)
     float s1 = 0.f, s2 = 0.f;
     float4 ov[MPW];
 #pragma unroll
@@ -2226,6 +2231,7 @@ __global__ __launch_bounds__(512, 2) void d3_pull_k(const D3Pull p) {
           __builtin_amdgcn_sched_barrier(0);
         }
         // epilogue of layer j: ReLU mask of the layer's BatchNorm output, BN-backward sums, gamma-weighted sum
+        mfma_drain();  // wait states between the MFMA chain and the first accumulator read (split16.h)
 #ifdef RLN_DIAG
         asm volatile("" ::"v"(acc[0][0]), "v"(acc[MT - 1][3]));
 #endif

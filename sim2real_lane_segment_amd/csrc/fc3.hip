@@ -100,6 +100,7 @@ __global__ __launch_bounds__(256, 2) void f3_fwd_k(const F3Fwd p) {
         f32x4 acc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = mfma_split<DT, NP>(A, bf[t], f32x4{0.f, 0.f, 0.f, 0.f});
+        mfma_drain();  // (the accumulators are read right away: see split16.h)
         const float4 b4 = *reinterpret_cast<const float4*>(btab + m * 16 + kb4);
         const float bia[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
@@ -253,6 +254,7 @@ __global__ __launch_bounds__(256, 2) void f3_wgrad_k(const F3Wgrad p) {
       }
     }
   }
+mfma_drain();  // wait states between the MFMA chain and the first accumulator read (split16.h)
   // ---- block reduction (fixed order) and store: acc[m][i][r] = dW[o = 16m + 4kb + r][k = 16i + n16] ----
 #pragma unroll
   for (int m = 0; m < F3_MT; ++m)

@@ -225,6 +225,7 @@ __global__ __launch_bounds__(512, 2) void p1_fwd_k(const P1Fwd p) {
       }
     }
     // ---- epilogue ----
+    mfma_drain();  // wait states between the MFMA chain and the first accumulator read (split16.h)
     int kb4 = 4 * kb;
     asm volatile("" : "+v"(kb4));  // per-iteration opaque: keeps the 64 channel addresses out of loop-invariant registers
     if (dbg & 4) {
@@ -498,6 +499,7 @@ __global__ __launch_bounds__(512, 2) void p1_dgrad_k(const P1Dgrad p) {
       }
     }
     // ---- epilogue ----
+    mfma_drain();  // wait states between the MFMA chain and the first accumulator read (split16.h)
     int kb4 = 4 * kb;
     asm volatile("" : "+v"(kb4));  // per-iteration opaque: keeps the channel addresses out of loop-invariant registers
 #pragma unroll
@@ -837,6 +839,7 @@ __global__ __launch_bounds__(256, 2) void p1_wgrad_k(const P1Wgrad p) {
     step(s, rawA);
     if (s + 1 < slab_end) step(s + 1, rawB);
   }
+mfma_drain();  // wait states between the MFMA chain and the first accumulator read (split16.h)
   // ---- store: acc[m][i][r] = dW[o = 16*(og*mo+m) + 4*kb + r][c = cch[i]] ----
   float* dst = p.partial + (long long)range * p.Cout * p.Cin;
 #pragma unroll

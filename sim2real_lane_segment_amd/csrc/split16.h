@@ -115,6 +115,16 @@ __device__ __forceinline__ float row16_sum(float v) {
 
 // LDS float add without return value (ds_add_f32): nothing to wait for.  Used for per-wave statistics slots that one wave
 // owns, so the issue order is the summation order (deterministic).
+// Wait states between the last MFMA of a dependent chain and the first ordinary read of its accumulator.  With the three-
+// part first convolution -- whose epilogue reads the accumulators at once -- the compiler (ROCm 7.2, gfx950) placed
+// `s_nop 6` + one instruction there, and rows 13 / 15 of the 16x16 tile (the rows a 16x16x32 MFMA writes in its last
+// pass) came back different from run to run (tools/forward_bisect.py).  Sixteen explicit wait states after the chain.
+__device__ __forceinline__ void mfma_drain() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 15");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 __device__ __forceinline__ void lds_add_f32(float* p, float v) {
   (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
