@@ -117,8 +117,9 @@ static void c3_group_plan(int m_tiles, int ksteps, int np, int* mt, int* groups)
 // =============================================================================================
 // WT: wave tiles a wave multiplies per pass.  WT = 2 shares every LDS weight-fragment read between two tiles but needs
 // ~310 VGPRs at two parts: 58 spilled registers, reloaded inside the K loop -- and the kernel was NOT bitwise repeatable
-// (tools/tu_stress.py: 21 of 3000 launches with one wave tile's outputs and sums changed; the spilled registers of
-// co-resident waves are the only state that is not in this source).  WT = 1 fits the register file without scratch.
+// (tools/tu_stress.py: 21 of 3000 launches with one wave tile's outputs and sums changed, always MFMA rows 13 / 15: the
+// accumulators were spilled too soon after the MFMA that wrote them -- see mfma_drain() in split16.h).  WT = 1 fits the
+// register file without scratch.
 template <int NP, int DT, int XT, int OT, int WT>
 __global__ __launch_bounds__(512, 2) void c3_fwd_k(const C3Fwd p) {
   extern __shared__ __align__(16) unsigned char smem[];
